@@ -1,0 +1,116 @@
+"""Pin the oracle (CPU restatement) against vectors produced by the reference itself
+(tests/golden/gen_golden.py, run in the build container with /root/reference imported)."""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import hat_oracle as O
+from super_resolution_amd import synth
+from helpers import GOLDEN, W_SEED, X_SEED, cfg_of, golden, max_abs, oracle_sd
+
+TOL = 1e-5  # restatement vs reference <= 1e-5 max-abs, fp32
+
+
+@pytest.mark.parametrize("name", ["tiny_x2", "tiny_ocabesc_x2", "HAT-S_x2", "HAT-S_x4", "HAT_x4", "HAT-L_x4"])
+def test_state_dict_surface(name):
+    with open(os.path.join(GOLDEN, "state_dict_surface.json")) as f:
+        surf = json.load(f)
+    spec = O.state_dict_spec(cfg_of(name))
+    ref = {k: (tuple(s), d) for k, s, d in surf[name]}
+    assert set(spec) == set(ref)
+    for k, (shape, dt) in spec.items():
+        assert ref[k] == (shape, str(dt)), k
+    nparams = sum(int(np.prod(s)) for k, (s, d) in spec.items() if d == torch.float32)
+    assert nparams == surf[name + ":nparams"]
+
+
+@pytest.mark.parametrize("ws,file", [(16, "rpi_ws16.npz"), (8, "rpi_ws8.npz")])
+def test_rpi_tables_bit_exact(ws, file):
+    g = golden(file)
+    assert torch.equal(O.rpi_sa(ws), torch.from_numpy(g["sa"]))
+    oca = O.rpi_oca(ws, 0.5)
+    assert torch.equal(oca, torch.from_numpy(g["oca"]))
+    assert int(oca.min()) < 0  # negative indices are part of the contract
+
+
+@pytest.mark.parametrize("name", ["tiny_x2", "tiny_x4", "tiny_x3", "tiny_ocabesc_x2", "hats_1g_x4", "hat_1g_x2"])
+def test_whole_model(name):
+    g = golden(f"whole_{name}.npz")
+    cfg, sd = oracle_sd(name)
+    x = synth.synth_input(X_SEED, tuple(g["x_shape"]))
+    y = O.hat_forward(x, sd, cfg)
+    assert y.shape == g["y"].shape
+    assert max_abs(y, g["y"]) <= TOL
+
+
+def test_cfg1_hats_x2_64():
+    g = golden("whole_HAT-S_x2_64.npz")
+    cfg, sd = oracle_sd("HAT-S_x2")
+    y = O.hat_forward(synth.synth_input(X_SEED, (1, 3, 64, 64)), sd, cfg)
+    assert max_abs(y, g["y"]) <= TOL
+
+
+@pytest.mark.parametrize("name", ["hats_1g_x4", "hat_1g_x2"])
+def test_blocks(name):
+    g = golden(f"blocks_{name}.npz")
+    cfg, sd = oracle_sd(name)
+    hw = tuple(int(v) for v in g["hw"])
+    C = cfg["embed_dim"]
+    t = synth.normal(X_SEED, "tokens", (1, hw[0] * hw[1], C))
+    p = "layers.0.residual_group.blocks.0"
+    n = O._ln(t, sd, p + ".norm1")
+    n_img = O._tok2img(n, hw)
+    assert max_abs(O.cab(n_img, sd, p + ".conv_block"), g["cab0"]) <= TOL
+    esc = O.esc_conv_attn(n_img, sd[p + ".esc_attn.plk_filter"], sd, p + ".esc_attn.core", cfg["esc_pdim"])
+    assert max_abs(O._img2tok(esc), g["esc0"]) <= TOL
+    assert max_abs(O.gated_dconv_ffn(t, hw, sd, p + ".mlp"), g["ffn0"]) <= TOL
+    assert max_abs(O.hab(t, hw, sd, p, cfg), g["hab0"]) <= TOL
+    rpi = sd["relative_position_index_OCA"]
+    o = O.ocab(t, hw, sd, "layers.0.residual_group.overlap_attn", rpi, cfg, cfg["num_heads"][0])
+    assert max_abs(o, g["ocab"]) <= TOL
+    r = O.rhag(t, hw, sd, "layers.0", rpi, cfg, cfg["depths"][0], cfg["num_heads"][0])
+    assert max_abs(r, g["rhag"]) <= 2 * TOL
+
+
+@pytest.mark.parametrize("name", ["tiny_x2", "tiny_x4"])
+def test_tile_loop(name):
+    g = golden(f"tiled_{name}.npz")
+    cfg, sd = oracle_sd(name)
+    s = cfg["upscale"]
+    x = synth.synth_input(X_SEED, tuple(g["x_shape"]))
+    img, ph, pw = O.pre_process(x, cfg["window_size"])
+    ts, tp = (int(v) for v in g["tile"])
+    y = O.post_process(O.tile_process(img, lambda z: O.hat_forward(z, sd, cfg), s, ts, tp), ph, pw, s)
+    assert y.shape == g["y"].shape
+    assert max_abs(y, g["y"]) <= TOL
+
+
+def test_window_multiple_required():
+    cfg, sd = oracle_sd("tiny_x2")
+    with pytest.raises(RuntimeError):
+        O.hat_forward(torch.rand(1, 3, 20, 16), sd, cfg)  # reference raises too
+
+
+def test_batch_is_per_sample_loop():
+    """reference eval is B=1 only; B>1 is defined as the loop of B=1 calls."""
+    cfg, sd = oracle_sd("tiny_x2")
+    x = synth.synth_input(3, (2, 3, 16, 16))
+    y = O.hat_forward(x, sd, cfg)
+    y0 = torch.cat([O.hat_forward(x[i:i + 1], sd, cfg) for i in range(2)])
+    assert max_abs(y, y0) <= 1e-5
+
+
+def test_psnr_known_answers():
+    """No metric fixtures exist in the reference: pin with hand-computed answers."""
+    a = np.full((16, 16, 3), 100, np.uint8)
+    assert O.psnr_y(a, a.copy(), 2) == float("inf")
+    b = a.copy()
+    b[..., :] = 101  # +1 on R,G,B -> dY = (65.481+128.553+24.966)/255 = 0.858823...
+    d = (65.481 + 128.553 + 24.966) / 255.0
+    assert abs(O.psnr_y(a, b, 2) - 10 * np.log10(255.0 ** 2 / d ** 2)) < 1e-3
+    t = torch.tensor([[[[0.5, 1.2], [-0.1, 0.25]]]]).repeat(1, 3, 1, 1)
+    img = O.tensor2img_rgb(t)
+    assert img.dtype == np.uint8 and img[0, 0, 0] == 128 and img[0, 1, 0] == 255 and img[1, 0, 0] == 0 and img[1, 1, 0] == 64
