@@ -1,0 +1,142 @@
+/*
+ * hat_mi355x.h — C ABI of libhat_mi355x.so: hand-written gfx950 (MI355X / CDNA4) kernels for the
+ * forward pass of the HAT super-resolution network of imjaegyun/super_resolution.
+ *
+ * The reference implements this path in pure PyTorch (no FFI exists upstream); each entry point
+ * below replaces a group of ATen calls inside `HAT.forward`.  File:line references are relative
+ * to /root/reference/HAT.  INTEGRATION.md shows the ctypes binding a maintainer adds on the
+ * reference side.
+ *
+ * Conventions
+ *   - every function returns 0 on success, a negative HAT_E* code on a bad argument or the
+ *     (positive) hipError_t of a failed launch; the Python host turns non-zero into RuntimeError;
+ *   - all pointers are DEVICE pointers owned by the caller; nothing is allocated, freed or
+ *     synchronised inside; kernels are enqueued on `stream` (a hipStream_t passed as void*);
+ *   - activations are channel-last ("tokens": (B, H, W, C) == the reference's (B, N, C) layout,
+ *     hat_arch.py:571-575); `dtype` selects the storage/MFMA operand type of T-typed buffers:
+ *     HAT_F32 (exact fp32 MFMA, parity path) or HAT_BF16 (bf16 MFMA operands, fp32 accumulate);
+ *   - the residual stream, LayerNorm statistics, softmax and all accumulations are fp32.
+ */
+#ifndef HAT_MI355X_H
+#define HAT_MI355X_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define HAT_ABI_VERSION 1
+
+enum { HAT_F32 = 0, HAT_BF16 = 1 };
+enum { HAT_EINVAL = -1, HAT_ELDS = -2, HAT_EUNSUPPORTED = -3 };
+
+/* activation codes */
+enum { HAT_ACT_NONE = 0, HAT_ACT_GELU = 1 /* exact erf, nn.GELU() */, HAT_ACT_LRELU = 2 /* slope 0.01 */ };
+/* conv input modes */
+enum { HAT_X_NHWC_T = 0, HAT_X_NHWC_F32 = 1, HAT_X_NCHW_F32_MEAN = 2 };
+/* conv output modes */
+enum { HAT_O_NHWC_T = 0, HAT_O_NHWC_F32 = 1, HAT_O_PIXSHUF_T = 2, HAT_O_NCHW_F32 = 3 };
+
+/*
+ * Implicit-GEMM convolution / pointwise linear on channel-last data with a fused epilogue:
+ *     out[p, n] = epi( sum_{tap, ci} X[p + tap, ci] * Wp[n, tap * Cin_p + ci] + bias[n] )
+ * zero padding ksize/2, stride 1.  Replaces (ksize == 1) nn.Linear / 1x1 nn.Conv2d:
+ * hat_arch.py:111,117 (FFN fc1/fc2), :347,350,391 (OCAB q/kv/proj), :309-313 (OCAB MLP),
+ * esc_arch.py:144 (ESC aggr); (ksize == 3) hat_arch.py:84,86 (CAB), :544 (RHAG conv), :673,747,
+ * 754,757 (head/tail), :598,601 (Upsample convs, with nn.PixelShuffle :599,602 folded into the
+ * store); (ksize == 13) esc_arch.py:122-123 (large-kernel conv + dynamic depthwise conv, the
+ * latter folded into per-sample weights by hat_esc_weights).
+ *
+ * Wp is packed [n_slices * nt * 16][Kpad] in T with K index = tap * Cin_p + ci,
+ * Cin_p = round_up(Cin, 8), Kpad = round_up(ksize^2 * Cin_p, KC), KC = 64 (bf16) / 32 (f32);
+ * zero padded.  epi: v = acc + bias[n]; v = act(v); v += r1[p, n] (fp32, optional);
+ * v += r2scale[n] * r2[p, n] (T, optional); store by out_mode; optional per-tile column sums
+ * of v (for the ECA global average pool, hat_arch.py:73).
+ */
+typedef struct HatConvDesc {
+    const void* x;        /* main input */
+    const void* x0;       /* optional: channels [0, c_split) are read from x0 (NHWC T, ldx0) */
+    const void* w;        /* packed weights (T) */
+    const float* bias;    /* [n_slices*nt*16] fp32, zero padded */
+    void* out;
+    const float* r1;      /* optional fp32 residual, NHWC stride ldr1 */
+    const void* r2;       /* optional T residual, NHWC stride ldr2, scaled per channel by r2scale */
+    const float* r2scale; /* [B][r2scale_bstride] fp32 */
+    float* colsum;        /* optional [B][tiles][n_slices*nt*16] per-tile column sums */
+    int32_t B, H, W;
+    int32_t Cin, ldx, x_mode;
+    int32_t c_split, ldx0;
+    int32_t ksize, Kpad;
+    int32_t nt, n_slices;
+    int64_t w_bstride;    /* elements between per-sample weight sets (0 = shared) */
+    int32_t n_store;      /* channels actually stored (multiple of 4 unless out_mode NCHW) */
+    int32_t ldo, out_mode, act;
+    int32_t ldr1, ldr2, r2scale_bstride;
+    int32_t ps_r;         /* pixel-shuffle factor for HAT_O_PIXSHUF_T */
+    float in_scale, out_scale;
+    float mean[4];        /* HAT_X_NCHW_F32_MEAN: x = (x - mean[c]) * in_scale;  HAT_O_NCHW_F32: v*out_scale + mean[n] */
+    int32_t dtype;
+} HatConvDesc;
+
+/* Number of spatial tiles hat_conv uses for (H, W, Cin, ksize, nt, dtype): the leading dimension of `colsum`. */
+int hat_conv_tiles(const HatConvDesc* d, int32_t* tiles_out);
+int hat_conv(const HatConvDesc* d, void* stream);
+
+/*
+ * LayerNorm over the channel dimension (eps 1e-5, affine), fp32 in -> T or fp32 out
+ * (nn.LayerNorm at hat_arch.py:209,214,291,306,743 and PatchEmbed.norm :573-574).
+ * Optionally emits per-block partial sums of the first `gap_c` output channels
+ * (the AdaptiveAvgPool2d(1) feeding the ESC dynamic kernel, esc_arch.py:96,121):
+ * gap_partial[b][blk][16], blk < hat_layernorm_blocks().
+ */
+int hat_layernorm_blocks(void);
+int hat_layernorm(const float* x, void* y, const float* gamma, const float* beta, float* gap_partial,
+                  int32_t B, int64_t npix, int32_t C, int32_t ldy, int32_t out_f32, int32_t gap_c,
+                  int32_t dtype, void* stream);
+
+/*
+ * ESC per-sample conv weights (esc_arch.py:95-100,121-123): p = mean(gap partials);
+ * dk = W2 * gelu(W1 * p + b1) + b2 (pdim*9 values); Wp[b][co][tap*Cin_p + ci] =
+ * T( plk_packed[co][tap*Cin_p+ci] + (co == ci && tap in central 3x3 ? dk[co*9 + ..] : 0) ).
+ */
+int hat_esc_weights(const float* gap_partial, int32_t nblk, int64_t npix, const float* w1, const float* b1,
+                    const float* w2, const float* b2, const float* plk_packed, void* w_out, int32_t B,
+                    int32_t pdim, int32_t ksize, int32_t Kpad, int32_t dtype, void* stream);
+
+/*
+ * ECA channel attention scale (hat_arch.py:73-77) times conv_scale (:236):
+ * scale[b][c] = conv_scale * sigmoid( conv1d_k(mean_pixels(c2))[c] ), from hat_conv's colsum.
+ * `tmp` is fp32 scratch of B*32*ldc floats.
+ */
+int hat_eca_scale(const float* colsum, int32_t tiles, int32_t ldc, int64_t npix, const float* wk, int32_t k,
+                  float conv_scale, float* tmp, float* scale, int32_t B, int32_t C, void* stream);
+
+/*
+ * Depthwise 3x3 (+bias, zero pad) on 2*hid channels, chunk(2), a * SiLU(g)   (hat_arch.py:112-116).
+ * u: (B,H,W,ldu) T with 2*hid channels; wdw packed [9][2*hid] fp32; out (B,H,W,ldo) T with hid channels.
+ */
+int hat_dwconv_gate(const void* u, const float* wdw, const float* bdw, void* out, int32_t B, int32_t H,
+                    int32_t W, int32_t hid, int32_t ldu, int32_t ldo, int32_t dtype, void* stream);
+
+/*
+ * Overlapping cross-attention core (hat_arch.py:353-388): per 'ws x ws' query window and head,
+ * softmax(q k^T + RPB) v over the 'wse x wse' key window (stride ws, zero padded, NOT masked).
+ * q: (B,H,W,ldq) T (already multiplied by head_dim^-0.5), kv: (B,H,W,ldkv) T with k at channel 0
+ * and v at channel C; bias_rot: [heads][(ws+wse-1)^2] fp32, the relative-position-bias table
+ * rotated so that index (kh-qh+ws-1)*(ws+wse-1) + (kw-qw+ws-1) is non-negative (the reference's
+ * negative-index wraparound, hat_arch.py:378, is applied when the table is packed).
+ * out: (B,H,W,ldo) T in window_reverse order (:387-388).
+ */
+int hat_ocab_attention(const void* q, const void* kv, const float* bias_rot, void* out, int32_t B, int32_t H,
+                       int32_t W, int32_t C, int32_t heads, int32_t ws, int32_t wse, int32_t ldq,
+                       int32_t ldkv, int32_t ldo, int32_t dtype, void* stream);
+
+int hat_abi_version(void);
+/* name of the architecture the code objects in this library were compiled for ("gfx950") */
+const char* hat_target_arch(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* HAT_MI355X_H */

@@ -1,0 +1,97 @@
+"""ctypes binding of libhat_mi355x.so (the C ABI declared in include/hat_mi355x.h).
+
+There is NO fallback: if the library is missing, cannot be loaded, or an entry point is absent,
+every use raises.  Build it with `python -m super_resolution_amd.build` (hipcc, gfx950).
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import threading
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libhat_mi355x.so")
+
+HAT_F32, HAT_BF16 = 0, 1
+ACT_NONE, ACT_GELU, ACT_LRELU = 0, 1, 2
+X_NHWC_T, X_NHWC_F32, X_NCHW_F32_MEAN = 0, 1, 2
+O_NHWC_T, O_NHWC_F32, O_PIXSHUF_T, O_NCHW_F32 = 0, 1, 2, 3
+
+_ERRORS = {-1: "HAT_EINVAL (bad argument)", -2: "HAT_ELDS (tile does not fit in 160 KiB LDS)",
+           -3: "HAT_EUNSUPPORTED (shape not instantiated)"}
+
+
+class HatConvDesc(C.Structure):
+    """Mirror of `struct HatConvDesc` (include/hat_mi355x.h) — field order and types must match."""
+    _fields_ = [
+        ("x", C.c_void_p), ("x0", C.c_void_p), ("w", C.c_void_p), ("bias", C.c_void_p),
+        ("out", C.c_void_p), ("r1", C.c_void_p), ("r2", C.c_void_p), ("r2scale", C.c_void_p), ("colsum", C.c_void_p),
+        ("B", C.c_int32), ("H", C.c_int32), ("W", C.c_int32),
+        ("Cin", C.c_int32), ("ldx", C.c_int32), ("x_mode", C.c_int32),
+        ("c_split", C.c_int32), ("ldx0", C.c_int32),
+        ("ksize", C.c_int32), ("Kpad", C.c_int32),
+        ("nt", C.c_int32), ("n_slices", C.c_int32),
+        ("w_bstride", C.c_int64),
+        ("n_store", C.c_int32),
+        ("ldo", C.c_int32), ("out_mode", C.c_int32), ("act", C.c_int32),
+        ("ldr1", C.c_int32), ("ldr2", C.c_int32), ("r2scale_bstride", C.c_int32),
+        ("ps_r", C.c_int32),
+        ("in_scale", C.c_float), ("out_scale", C.c_float),
+        ("mean", C.c_float * 4),
+        ("dtype", C.c_int32),
+    ]
+
+
+# name -> (restype, argtypes); every symbol declared in include/hat_mi355x.h
+SIGNATURES = {
+    "hat_abi_version": (C.c_int, []),
+    "hat_target_arch": (C.c_char_p, []),
+    "hat_conv_tiles": (C.c_int, [C.POINTER(HatConvDesc), C.POINTER(C.c_int32)]),
+    "hat_conv": (C.c_int, [C.POINTER(HatConvDesc), C.c_void_p]),
+    "hat_layernorm_blocks": (C.c_int, []),
+    "hat_layernorm": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int64,
+                                C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_void_p]),
+    "hat_esc_weights": (C.c_int, [C.c_void_p, C.c_int32, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                  C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_void_p]),
+    "hat_eca_scale": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_int64, C.c_void_p, C.c_int32, C.c_float,
+                                C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p]),
+    "hat_dwconv_gate": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32,
+                                  C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_void_p]),
+    "hat_ocab_attention": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32,
+                                     C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32,
+                                     C.c_int32, C.c_void_p]),
+}
+
+_lib = None
+_lock = threading.Lock()
+
+
+def load():
+    """Load the library (once) and bind every entry point; raise if anything is missing."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    with _lock:
+        if _lib is not None:
+            return _lib
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError(
+                f"{LIB_PATH} not found: the HIP kernels are not built. Run `python -m super_resolution_amd.build` "
+                "(needs hipcc). There is no CPU fallback for the HAT forward pass.")
+        lib = C.CDLL(LIB_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(lib, name, None)
+            if fn is None:
+                raise RuntimeError(f"{LIB_PATH} does not export `{name}` (stale build?)")
+            fn.restype = res
+            fn.argtypes = args
+        if lib.hat_abi_version() != 1:
+            raise RuntimeError(f"ABI version mismatch: library {lib.hat_abi_version()}, binding 1")
+        _lib = lib
+    return _lib
+
+
+def check(rc: int, what: str):
+    if rc != 0:
+        msg = _ERRORS.get(rc, f"hipError_t {rc}")
+        raise RuntimeError(f"{what} failed: {msg}")

@@ -1,0 +1,209 @@
+// hat_attn.hip — overlapping cross-attention (OCAB) core on gfx950.   Contract: include/hat_mi355x.h
+// (hat_ocab_attention); reference: hat/archs/hat_arch.py:353-388.
+//
+// One workgroup (4 waves) per (window, head).  K (nk x d, zero padded to 32 channels) and V
+// (transposed: 32 x nk) of the (wse x wse) key window live in LDS, out-of-image keys are exact
+// zeros (the reference unfolds AFTER the biased projection with zero padding and does not mask).
+// Each wave owns 16-query tiles: S^T = K.Q^T via MFMA 16x16 (A = keys, B = queries) so one lane
+// holds, for ONE query, 4 keys of every key tile; softmax statistics are per-lane loops plus two
+// cross-lane shuffles; P^T feeds the second MFMA (O^T = V^T.P^T) straight from the accumulator
+// registers — the contraction index (key) ordering inside a 32-wide k-step is permuted
+// identically for both operands, so no LDS round trip or lane movement is needed for P.
+#include "hat_common.h"
+
+namespace {
+
+template <typename T> struct alignas(4 * sizeof(T)) Q4 { T v[4]; };  // 4 consecutive elements, one LDS read
+
+template <typename T> __device__ __forceinline__ float exp_t(float x);
+template <> __device__ __forceinline__ float exp_t<float>(float x) { return expf(x); }
+template <> __device__ __forceinline__ float exp_t<bf16_t>(float x) { return __expf(x); }
+
+template <typename T, int NKT, int KCH>
+__global__ __launch_bounds__(256) void ocab_attn_kernel(const T* __restrict__ q, const T* __restrict__ kv,
+                                                        const float* __restrict__ bias_rot, T* __restrict__ out, int H, int W,
+                                                        int C, int heads, int ws, int wse, int ldq, int ldkv, int ldo) {
+    using M = MT<T>;
+    constexpr int NK = NKT * 16;
+    static_assert(NKT % KCH == 0, "key tiles must split evenly into chunks");
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int d = C / heads;
+    const int dk8 = (d + 7) & ~7;                      // K channels kept in LDS (zero padded d..dk8)
+    const int dv = (d + 1) & ~1;                        // V^T rows kept in LDS
+    const int ldk = lds_row_elems(dk8, sizeof(T));
+    const int ldv = lds_row_elems(NK, sizeof(T));
+    T* Ks = reinterpret_cast<T*>(smem);
+    T* Vt = Ks + (size_t)NK * ldk;
+    float* tab = reinterpret_cast<float*>(smem + (((size_t)NK * ldk + (size_t)dv * ldv) * sizeof(T) + 15) / 16 * 16);
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = lane >> 4, c16 = lane & 15;
+    const int wx = blockIdx.x, wy = blockIdx.y;
+    const int b = blockIdx.z / heads, h = blockIdx.z - b * heads;
+    const int Mr = ws + wse - 1;
+    const int pad = (wse - ws) / 2;
+    const size_t img = (size_t)b * H * W;
+
+    for (int i = tid; i < Mr * Mr; i += 256) tab[i] = bias_rot[(size_t)h * Mr * Mr + i];
+
+    // ---- stage K [key][32] and V^T [32][key]; 2 channels per work item -----------------------
+    const int cpk = dk8 / 2;  // channel pairs per key
+    for (int i = tid; i < NK * cpk; i += 256) {
+        const int key = i / cpk, c = (i - key * cpk) * 2;
+        const int kh = key / wse, kw = key - kh * wse;
+        const int y = wy * ws - pad + kh, x = wx * ws - pad + kw;
+        T k0 = to_T<T>(0.f), k1 = k0, v0 = k0, v1 = k0;
+        if (c < d && y >= 0 && y < H && x >= 0 && x < W) {
+            const T* p = kv + (img + (size_t)y * W + x) * ldkv + h * d + c;
+            k0 = p[0]; k1 = p[1];
+            v0 = p[C]; v1 = p[C + 1];
+        }
+        Ks[key * ldk + c] = k0; Ks[key * ldk + c + 1] = k1;
+        if (c < dv) { Vt[c * ldv + key] = v0; Vt[(c + 1) * ldv + key] = v1; }
+    }
+    __syncthreads();
+
+    const int nqt = (ws * ws) / 16;
+    for (int qt = wave; qt < nqt; qt += 4) {
+        // ---- Q fragment (B operand): this lane's query, channels 8g..8g+7 --------------------
+        const int qi = qt * 16 + c16;
+        const int qy = qi / ws, qx = qi - qy * ws;
+        const size_t qpix = img + (size_t)(wy * ws + qy) * W + (wx * ws + qx);
+        typename M::frag_t qf;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int c = 8 * g + j;
+            qf[j] = c < d ? q[qpix * ldq + h * d + c] : to_T<T>(0.f);
+        }
+        // ---- online softmax over chunks of KCH key tiles (O is only d <= 32 wide, so the rescale
+        //      is 8 registers; this keeps the live S tile set at KCH*4 registers) ------------------
+        f32x4 o[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
+        float mrun = -3.0e38f, l = 0.f;
+        int kh = (4 * g) / wse, kw = 4 * g - kh * wse;  // the lane's 4 keys of a tile share one key row (wse % 4 == 0)
+#pragma unroll 1
+        for (int ch = 0; ch < NKT / KCH; ++ch) {
+            const int kt0 = ch * KCH;
+            // S^T tiles: s[t][r] = S[key = 16 (kt0+t) + 4g + r][query c16]
+            f32x4 s[KCH];
+#pragma unroll
+            for (int t = 0; t < KCH; ++t) {
+                // channel groups beyond dk8 are clamped: they meet a zero Q fragment, so contribute 0
+                const typename M::frag_t kf = M::load(Ks + ((kt0 + t) * 16 + c16) * ldk + (8 * g < dk8 ? 8 * g : dk8 - 8));
+                s[t] = M::mma(kf, qf, f32x4{0.f, 0.f, 0.f, 0.f});
+            }
+            float mx = -3.0e38f;
+#pragma unroll
+            for (int t = 0; t < KCH; ++t) {
+                const float* tb = tab + (kh - qy + ws - 1) * Mr + (kw - qx + ws - 1);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    s[t][r] += tb[r];
+                    mx = fmaxf(mx, s[t][r]);
+                }
+                kw += 16;
+                while (kw >= wse) { kw -= wse; ++kh; }
+            }
+            mx = fmaxf(mx, __shfl_xor(mx, 16));
+            mx = fmaxf(mx, __shfl_xor(mx, 32));
+            const float mnew = fmaxf(mrun, mx);
+            const float alpha = exp_t<T>(mrun - mnew);
+            mrun = mnew;
+            float lsum = 0.f;
+#pragma unroll
+            for (int t = 0; t < KCH; ++t) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const float p = exp_t<T>(s[t][r] - mnew);
+                    s[t][r] = p;
+                    lsum += p;
+                }
+            }
+            l = l * alpha + lsum;  // per-lane partial; reduced across the 4 lane groups after the loop
+            o[0] *= alpha;
+            o[1] *= alpha;
+            // O^T += V^T . P^T : k-slot (g, j) = key 32 kk + 4g + j (j<4) | 32 kk + 16 + 4g + (j-4)
+#pragma unroll
+            for (int kk = 0; kk < (KCH + 1) / 2; ++kk) {
+                const bool has_b = (2 * kk + 1 < KCH);
+                const int kb = has_b ? 2 * kk + 1 : 2 * kk;
+                typename M::frag_t pf;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    pf[j] = to_T<T>(s[2 * kk][j]);
+                    pf[j + 4] = has_b ? to_T<T>(s[kb][j]) : to_T<T>(0.f);
+                }
+#pragma unroll
+                for (int ct = 0; ct < 2; ++ct) {
+                    // rows >= d are clamped: their outputs are never stored
+                    const int vrow = (ct * 16 + c16 < dv) ? ct * 16 + c16 : dv - 1;
+                    const T* vr = Vt + (size_t)vrow * ldv + (kt0 + 2 * kk) * 16 + 4 * g;
+                    const Q4<T> va = *reinterpret_cast<const Q4<T>*>(vr);
+                    const Q4<T> vb = *reinterpret_cast<const Q4<T>*>(vr + (has_b ? 16 : 0));
+                    typename M::frag_t vf;
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        vf[j] = va.v[j];
+                        vf[j + 4] = has_b ? vb.v[j] : to_T<T>(0.f);
+                    }
+                    o[ct] = M::mma(vf, pf, o[ct]);
+                }
+            }
+        }
+        l += __shfl_xor(l, 16);
+        l += __shfl_xor(l, 32);
+        // ---- store: lane holds channels ct*16 + 4g + r of query c16 -----------------------------
+        const float inv = 1.0f / l;
+#pragma unroll
+        for (int ct = 0; ct < 2; ++ct) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int c = ct * 16 + 4 * g + r;
+                if (c < d) out[qpix * ldo + h * d + c] = to_T<T>(o[ct][r] * inv);
+            }
+        }
+    }
+}
+
+template <typename T, int NKT, int KCH>
+int launch_attn(const void* q, const void* kv, const float* bias_rot, void* out, int B, int H, int W, int C, int heads,
+                int ws, int wse, int ldq, int ldkv, int ldo, hipStream_t s) {
+    const int es = sizeof(T);
+    const int Mr = ws + wse - 1;
+    const int d = C / heads, dk8 = (d + 7) & ~7, dv = (d + 1) & ~1;
+    const size_t kvb = ((size_t)NKT * 16 * lds_row_elems(dk8, es) + (size_t)dv * lds_row_elems(NKT * 16, es)) * es;
+    const size_t lds = (kvb + 15) / 16 * 16 + (size_t)Mr * Mr * 4;
+    if (lds > HAT_LDS_MAX) return HAT_ELDS;
+    auto kern = ocab_attn_kernel<T, NKT, KCH>;
+    if (lds > 65536) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return (int)e;
+    }
+    dim3 grid(W / ws, H / ws, B * heads);
+    hipLaunchKernelGGL(kern, grid, dim3(256), lds, s, reinterpret_cast<const T*>(q), reinterpret_cast<const T*>(kv), bias_rot,
+                       reinterpret_cast<T*>(out), H, W, C, heads, ws, wse, ldq, ldkv, ldo);
+    return hat_check_launch();
+}
+
+}  // namespace
+
+extern "C" int hat_ocab_attention(const void* q, const void* kv, const float* bias_rot, void* out, int32_t B, int32_t H,
+                                  int32_t W, int32_t C, int32_t heads, int32_t ws, int32_t wse, int32_t ldq,
+                                  int32_t ldkv, int32_t ldo, int32_t dtype, void* stream) {
+    if (!q || !kv || !bias_rot || !out || B < 1 || heads < 1 || C % heads) return HAT_EINVAL;
+    if (ws < 4 || H % ws || W % ws || wse < ws || (wse - ws) % 2 || wse % 4 || (ws * ws) % 16 || (wse * wse) % 16) return HAT_EINVAL;
+    const int d = C / heads;
+    if (d > 32 || d % 2 || ldq < C || ldkv < 2 * C || ldo < C) return HAT_EINVAL;
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    const int nkt = wse * wse / 16;
+#define HAT_ATTN_CASE(TT, N, K) return launch_attn<TT, N, K>(q, kv, bias_rot, out, B, H, W, C, heads, ws, wse, ldq, ldkv, ldo, s)
+    if (dtype == HAT_BF16) {
+        if (nkt == 36) HAT_ATTN_CASE(bf16_t, 36, 12);
+        if (nkt == 9) HAT_ATTN_CASE(bf16_t, 9, 9);
+    } else if (dtype == HAT_F32) {
+        if (nkt == 36) HAT_ATTN_CASE(float, 36, 12);
+        if (nkt == 9) HAT_ATTN_CASE(float, 9, 9);
+    } else {
+        return HAT_EINVAL;
+    }
+#undef HAT_ATTN_CASE
+    return HAT_EUNSUPPORTED;  // window sizes other than 16/24 and 8/12 are not instantiated
+}

@@ -1,0 +1,109 @@
+// hat_common.h — device-side helpers shared by the gfx950 kernels (wave64, MFMA 16x16 tiles).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/hat_mi355x.h"
+
+typedef __bf16 bf16_t;
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));  // one 16-byte piece
+
+#define HAT_LDS_MAX 163840  // 160 KiB per workgroup on gfx950
+
+// ---------------------------------------------------------------------------------------------
+// MT<T>: one "k-step" of 32 along K on a 16x16 output tile.
+//   bf16: one v_mfma_f32_16x16x32_bf16; lane l holds A[row l&15][k = 8*(l>>4)+j], j = 0..7
+//   f32 : eight v_mfma_f32_16x16x4_f32; element j of every lane feeds MFMA j, which contracts
+//         over k = 8*g + j, g = l>>4 = 0..3 — the same (g, j) -> k map as bf16, so LDS layouts
+//         and fragment addressing are shared by both instantiations.  The f32 form is bit-wise
+//         an fp32 fmaf chain (exact-fp32 parity path), 1/16 of the bf16 rate.
+//   D layout (both): col = l & 15 (B's column), row = 4*(l>>4) + reg (A's row).
+// ---------------------------------------------------------------------------------------------
+template <typename T> struct MT;
+
+template <> struct MT<bf16_t> {
+    static constexpr int VEC = 8;   // elements per 16 bytes
+    static constexpr int KC = 64;   // K elements per staged weight chunk (128 B per row)
+    typedef bf16_t frag_t __attribute__((ext_vector_type(8)));
+    static __device__ __forceinline__ frag_t load(const bf16_t* p) { return *reinterpret_cast<const frag_t*>(p); }
+    static __device__ __forceinline__ frag_t zero() {
+        frag_t z;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) z[i] = (bf16_t)0.0f;
+        return z;
+    }
+    static __device__ __forceinline__ f32x4 mma(frag_t a, frag_t b, f32x4 c) {
+        return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
+    }
+};
+
+template <> struct MT<float> {
+    static constexpr int VEC = 4;
+    static constexpr int KC = 32;
+    typedef float frag_t __attribute__((ext_vector_type(8)));
+    static __device__ __forceinline__ frag_t load(const float* p) {
+        const f32x4 lo = *reinterpret_cast<const f32x4*>(p);
+        const f32x4 hi = *reinterpret_cast<const f32x4*>(p + 4);
+        frag_t r;
+        r[0] = lo[0]; r[1] = lo[1]; r[2] = lo[2]; r[3] = lo[3];
+        r[4] = hi[0]; r[5] = hi[1]; r[6] = hi[2]; r[7] = hi[3];
+        return r;
+    }
+    static __device__ __forceinline__ frag_t zero() {
+        frag_t z;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) z[i] = 0.0f;
+        return z;
+    }
+    static __device__ __forceinline__ f32x4 mma(frag_t a, frag_t b, f32x4 c) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) c = __builtin_amdgcn_mfma_f32_16x16x4f32(a[j], b[j], c, 0, 0, 0);
+        return c;
+    }
+};
+
+// conversions ---------------------------------------------------------------------------------
+template <typename T> __device__ __forceinline__ T to_T(float v);
+template <> __device__ __forceinline__ float to_T<float>(float v) { return v; }
+template <> __device__ __forceinline__ bf16_t to_T<bf16_t>(float v) { return (bf16_t)v; }  // RNE, v_cvt_pk_bf16_f32
+__device__ __forceinline__ float to_f(float v) { return v; }
+__device__ __forceinline__ float to_f(bf16_t v) { return (float)v; }
+
+// 4 consecutive T values <-> 4 floats
+template <typename T> struct Vec4;
+template <> struct Vec4<float> {
+    static __device__ __forceinline__ f32x4 load(const float* p) { return *reinterpret_cast<const f32x4*>(p); }
+    static __device__ __forceinline__ void store(float* p, f32x4 v) { *reinterpret_cast<f32x4*>(p) = v; }
+};
+template <> struct Vec4<bf16_t> {
+    typedef bf16_t v4 __attribute__((ext_vector_type(4)));
+    static __device__ __forceinline__ f32x4 load(const bf16_t* p) {
+        const v4 h = *reinterpret_cast<const v4*>(p);
+        f32x4 r;
+        r[0] = (float)h[0]; r[1] = (float)h[1]; r[2] = (float)h[2]; r[3] = (float)h[3];
+        return r;
+    }
+    static __device__ __forceinline__ void store(bf16_t* p, f32x4 v) {
+        v4 h;
+        h[0] = (bf16_t)v[0]; h[1] = (bf16_t)v[1]; h[2] = (bf16_t)v[2]; h[3] = (bf16_t)v[3];
+        *reinterpret_cast<v4*>(p) = h;
+    }
+};
+
+// LDS row stride (in elements) for rows of `n` elements of size `es`: a multiple of 16 bytes with
+// an ODD number of 16-byte slots, so 16 consecutive rows read at one k offset by ds_read_b128
+// spread over all 64 banks (cdna guide §2 / Guideline 4).
+__host__ __device__ inline int lds_row_elems(int n, int es) {
+    int slots = (n * es + 15) / 16;
+    if ((slots & 1) == 0) slots += 1;
+    return slots * 16 / es;
+}
+
+__device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
+
+static inline int hat_check_launch() {
+    hipError_t e = hipGetLastError();
+    return e == hipSuccess ? 0 : (int)e;
+}

@@ -1,0 +1,331 @@
+// hat_conv.hip — implicit-GEMM convolution / pointwise linear for channel-last activations on
+// gfx950, MFMA 16x16 tiles, fused epilogues.  See include/hat_mi355x.h (HatConvDesc) for the
+// contract and the reference lines each use replaces.
+//
+// Workgroup = WAVES waves; output tile = (WAVES*PT) rows x 16 columns of pixels x (NT*16) channels
+// per n-slice.  Orientation: MFMA A operand = packed weights (rows = output channel),
+// B operand = activations (columns = 16 consecutive pixels of one tile row), so a lane's four
+// accumulator registers are four CONSECUTIVE CHANNELS of one pixel (vector epilogue stores).
+//
+//   LDS:  Xs[(rows+2h) * (16+2h)][Cin_p (+pad)]   the haloed input tile, ALL input channels, staged once
+//         Ws[NT*16][KC (+pad)]                    one K-chunk of the weight slice, register-prefetched
+//   K is flat: k = tap * Cin_p + ci; a lane's 8-element k group never straddles a tap because
+//   Cin_p % 8 == 0, so each lane tracks its own (tap, ci) and reads its B fragment from the
+//   shifted pixel: no im2col buffer exists anywhere.
+#include "hat_common.h"
+
+namespace {
+
+struct TileCfg { int waves, pt; };
+
+__host__ inline size_t conv_lds_bytes(const HatConvDesc& d, int waves, int pt, int es, int kc) {
+    const int hl = d.ksize / 2;
+    const int cin_p = (d.Cin + 7) & ~7;
+    const size_t xs = (size_t)(waves * pt + 2 * hl) * (16 + 2 * hl) * lds_row_elems(cin_p, es) * es;
+    const size_t ws = (size_t)d.nt * 16 * lds_row_elems(kc, es) * es;
+    const size_t taps = ((size_t)d.ksize * d.ksize * 4 + 15) & ~(size_t)15;
+    return xs + ws + taps;
+}
+
+__host__ inline bool conv_pick(const HatConvDesc& d, TileCfg* out, size_t* lds) {
+    const int es = d.dtype == HAT_BF16 ? 2 : 4;
+    const int kc = d.dtype == HAT_BF16 ? 64 : 32;
+    const TileCfg cands[3] = {{8, 2}, {4, 2}, {4, 1}};
+    for (int i = 0; i < 3; ++i) {
+        const int rows = cands[i].waves * cands[i].pt;
+        if (i < 2 && d.H * 2 <= rows) continue;  // do not waste most of a tall tile on a short image
+        const size_t b = conv_lds_bytes(d, cands[i].waves, cands[i].pt, es, kc);
+        if (b <= HAT_LDS_MAX) { *out = cands[i]; *lds = b; return true; }
+    }
+    return false;
+}
+
+template <typename T, int WAVES, int PT, int NT>
+__global__ __launch_bounds__(WAVES * 64) void conv_kernel(const HatConvDesc d) {
+    using M = MT<T>;
+    constexpr int NTHR = WAVES * 64;
+    constexpr int TROWS = WAVES * PT;
+    constexpr int KC = M::KC;
+    constexpr int KS = KC / 32;
+    constexpr int VEC = M::VEC;
+    constexpr int WPIECES = NT * 16 * 8;  // 16-byte pieces per weight chunk (128 B per row)
+    constexpr int WPT = (WPIECES + NTHR - 1) / NTHR;
+
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6, g = lane >> 4, c16 = lane & 15;
+    const int ks_ = d.ksize;
+    const int hl = ks_ >> 1, TWH = 16 + 2 * hl, THH = TROWS + 2 * hl;
+    const int Cin = d.Cin, Cin_p = (Cin + 7) & ~7;
+    const int ldxs = lds_row_elems(Cin_p, sizeof(T));
+    const int ldws = lds_row_elems(KC, sizeof(T));
+    T* Xs = reinterpret_cast<T*>(smem);
+    T* Ws = Xs + (size_t)THH * TWH * ldxs;
+    int* tapoff = reinterpret_cast<int*>(Ws + NT * 16 * ldws);
+    float* cs = reinterpret_cast<float*>(Ws);  // column-sum scratch, reuses Ws after the K loop
+
+    const int b = blockIdx.z;
+    const int x0 = blockIdx.x * 16, y0 = blockIdx.y * TROWS;
+    const int H = d.H, W = d.W;
+    const int ntaps = ks_ * ks_;
+
+    for (int t = tid; t < ntaps; t += NTHR) tapoff[t] = (t / ks_) * TWH + (t % ks_);
+
+    // ---------------- stage the haloed input tile (all channels), zero filled ------------------
+    const int npixh = THH * TWH;
+    if (d.x_mode == HAT_X_NHWC_T) {
+        const T* xg = reinterpret_cast<const T*>(d.x);
+        const T* xg0 = reinterpret_cast<const T*>(d.x0);
+        const int ppp = Cin_p / VEC;
+        const int total = npixh * ppp;
+        for (int i = tid; i < total; i += NTHR) {
+            const int q = i / ppp, c = (i - q * ppp) * VEC;
+            const int qy = q / TWH, qx = q - qy * TWH;
+            const int y = y0 - hl + qy, x = x0 - hl + qx;
+            u32x4 v = {0u, 0u, 0u, 0u};
+            if (y >= 0 && y < H && x >= 0 && x < W && c < Cin) {
+                const size_t pix = ((size_t)b * H + y) * W + x;
+                const T* src = (xg0 != nullptr && c < d.c_split) ? xg0 + pix * d.ldx0 + c : xg + pix * d.ldx + c;
+                v = *reinterpret_cast<const u32x4*>(src);
+            }
+            *reinterpret_cast<u32x4*>(Xs + (size_t)q * ldxs + c) = v;
+        }
+    } else if (d.x_mode == HAT_X_NHWC_F32) {
+        const float* xg = reinterpret_cast<const float*>(d.x);
+        const int gpp = Cin_p / 4;
+        const int total = npixh * gpp;
+        for (int i = tid; i < total; i += NTHR) {
+            const int q = i / gpp, c = (i - q * gpp) * 4;
+            const int qy = q / TWH, qx = q - qy * TWH;
+            const int y = y0 - hl + qy, x = x0 - hl + qx;
+            f32x4 v = {0.f, 0.f, 0.f, 0.f};
+            if (y >= 0 && y < H && x >= 0 && x < W && c < Cin)
+                v = *reinterpret_cast<const f32x4*>(xg + (((size_t)b * H + y) * W + x) * d.ldx + c);
+            Vec4<T>::store(Xs + (size_t)q * ldxs + c, v);
+        }
+    } else {  // HAT_X_NCHW_F32_MEAN: (x - mean[c]) * in_scale, zero padding applied AFTER the shift
+        const float* xg = reinterpret_cast<const float*>(d.x);
+        const int total = npixh * Cin_p;
+        for (int i = tid; i < total; i += NTHR) {
+            const int q = i / Cin_p, c = i - q * Cin_p;
+            const int qy = q / TWH, qx = q - qy * TWH;
+            const int y = y0 - hl + qy, x = x0 - hl + qx;
+            float v = 0.f;
+            if (y >= 0 && y < H && x >= 0 && x < W && c < Cin)
+                v = (xg[(((size_t)b * Cin + c) * H + y) * W + x] - d.mean[c & 3]) * d.in_scale;
+            Xs[(size_t)q * ldxs + c] = to_T<T>(v);
+        }
+    }
+
+    const T* wg = reinterpret_cast<const T*>(d.w) + (size_t)b * d.w_bstride;
+    const int nchunks = d.Kpad / KC;
+    const int Npad = d.n_slices * NT * 16;
+    const size_t tile_id = (size_t)blockIdx.y * gridDim.x + blockIdx.x;
+    const size_t ntiles = (size_t)gridDim.x * gridDim.y;
+
+    for (int slice = 0; slice < d.n_slices; ++slice) {
+        f32x4 acc[NT][PT];
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+            for (int pt = 0; pt < PT; ++pt) acc[nt][pt] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+        const T* wslice = wg + (size_t)slice * NT * 16 * d.Kpad;
+        u32x4 wreg[WPT];
+        // register prefetch of one weight chunk (global -> VGPR now, VGPR -> LDS after the barrier)
+#define HAT_W_PREFETCH(chunk_)                                                                                        \
+    _Pragma("unroll") for (int j = 0; j < WPT; ++j) {                                                                 \
+        const int p_ = tid + j * NTHR;                                                                                \
+        if (WPIECES % NTHR == 0 || p_ < WPIECES)                                                                      \
+            wreg[j] = *reinterpret_cast<const u32x4*>(wslice + (size_t)(p_ >> 3) * d.Kpad + (size_t)(chunk_) * KC + (p_ & 7) * VEC); \
+    }
+#define HAT_W_COMMIT()                                                                                                \
+    _Pragma("unroll") for (int j = 0; j < WPT; ++j) {                                                                 \
+        const int p_ = tid + j * NTHR;                                                                                \
+        if (WPIECES % NTHR == 0 || p_ < WPIECES)                                                                      \
+            *reinterpret_cast<u32x4*>(Ws + (p_ >> 3) * ldws + (p_ & 7) * VEC) = wreg[j];                               \
+    }
+
+        // this lane's position in flat K: k = 8*g (+32 per k-step) -> (tap, ci)
+        int ci = 8 * g, tap = 0;
+        while (ci >= Cin_p) { ci -= Cin_p; ++tap; }
+
+        HAT_W_PREFETCH(0)
+        for (int chunk = 0; chunk < nchunks; ++chunk) {
+            HAT_W_COMMIT()
+            __syncthreads();  // Ws (and, first time, Xs / tapoff) visible
+            if (chunk + 1 < nchunks) { HAT_W_PREFETCH(chunk + 1) }
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) {
+                const int poff = tapoff[tap < ntaps ? tap : ntaps - 1];
+                typename M::frag_t bf[PT];
+#pragma unroll
+                for (int pt = 0; pt < PT; ++pt)
+                    bf[pt] = M::load(Xs + (size_t)((wave * PT + pt) * TWH + c16 + poff) * ldxs + ci);
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt) {
+                    const typename M::frag_t af = M::load(Ws + (nt * 16 + c16) * ldws + ks * 32 + 8 * g);
+#pragma unroll
+                    for (int pt = 0; pt < PT; ++pt) acc[nt][pt] = M::mma(af, bf[pt], acc[nt][pt]);
+                }
+                ci += 32;
+                while (ci >= Cin_p) { ci -= Cin_p; ++tap; }
+            }
+            __syncthreads();  // all waves done with Ws before the next commit / cs reuse
+        }
+
+        // ---------------------------------- epilogue ------------------------------------------
+        const int nbase = slice * NT * 16;
+        const bool want_cs = d.colsum != nullptr;
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) {
+            const int n = nbase + nt * 16 + 4 * g;  // first of this lane's 4 consecutive channels
+            const f32x4 bias = *reinterpret_cast<const f32x4*>(d.bias + n);
+            f32x4 csum = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int pt = 0; pt < PT; ++pt) {
+                const int y = y0 + wave * PT + pt, x = x0 + c16;
+                const bool valid = (y < H) && (x < W);
+                f32x4 v = acc[nt][pt] + bias;
+                if (d.act == HAT_ACT_GELU) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) v[r] = gelu_erf(v[r]);
+                } else if (d.act == HAT_ACT_LRELU) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) v[r] = v[r] >= 0.f ? v[r] : 0.01f * v[r];
+                }
+                if (valid && n < d.n_store) {
+                    const size_t pix = ((size_t)b * H + y) * W + x;
+                    if (d.r1 != nullptr) v += *reinterpret_cast<const f32x4*>(d.r1 + pix * d.ldr1 + n);
+                    if (d.r2 != nullptr) {
+                        const f32x4 rv = Vec4<T>::load(reinterpret_cast<const T*>(d.r2) + pix * d.ldr2 + n);
+                        const f32x4 sc = *reinterpret_cast<const f32x4*>(d.r2scale + (size_t)b * d.r2scale_bstride + n);
+                        v += sc * rv;
+                    }
+                    if (d.out_mode == HAT_O_NHWC_T) {
+                        Vec4<T>::store(reinterpret_cast<T*>(d.out) + pix * d.ldo + n, v);
+                    } else if (d.out_mode == HAT_O_NHWC_F32) {
+                        *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(d.out) + pix * d.ldo + n) = v;
+                    } else if (d.out_mode == HAT_O_PIXSHUF_T) {
+                        const int r_ = d.ps_r, cps = d.n_store / (r_ * r_);
+                        const int ij = n / cps, cc = n - ij * cps;
+                        const int i_ = ij / r_, j_ = ij - i_ * r_;
+                        const size_t opix = ((size_t)b * H * r_ + (size_t)y * r_ + i_) * ((size_t)W * r_) + (size_t)x * r_ + j_;
+                        Vec4<T>::store(reinterpret_cast<T*>(d.out) + opix * d.ldo + cc, v);
+                    } else {  // HAT_O_NCHW_F32
+#pragma unroll
+                        for (int r = 0; r < 4; ++r)
+                            if (n + r < d.n_store)
+                                reinterpret_cast<float*>(d.out)[(((size_t)b * d.n_store + n + r) * H + y) * W + x] =
+                                    v[r] * d.out_scale + d.mean[(n + r) & 3];
+                    }
+                }
+                if (want_cs && valid) csum += v;
+            }
+            if (want_cs) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    float s = csum[r];
+                    s += __shfl_xor(s, 1); s += __shfl_xor(s, 2); s += __shfl_xor(s, 4); s += __shfl_xor(s, 8);
+                    if (c16 == 0) cs[wave * (NT * 16) + nt * 16 + 4 * g + r] = s;
+                }
+            }
+        }
+        if (want_cs) {
+            __syncthreads();
+            for (int n = tid; n < NT * 16; n += NTHR) {
+                float s = 0.f;
+#pragma unroll
+                for (int w = 0; w < WAVES; ++w) s += cs[w * (NT * 16) + n];
+                d.colsum[((size_t)b * ntiles + tile_id) * Npad + nbase + n] = s;
+            }
+            __syncthreads();
+        }
+    }
+}
+
+template <typename T, int WAVES, int PT, int NT>
+int launch_conv(const HatConvDesc& d, size_t lds, hipStream_t stream) {
+    auto kern = conv_kernel<T, WAVES, PT, NT>;
+    if (lds > 65536) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return (int)e;
+    }
+    dim3 grid((d.W + 15) / 16, (d.H + WAVES * PT - 1) / (WAVES * PT), d.B);
+    hipLaunchKernelGGL(kern, grid, dim3(WAVES * 64), lds, stream, d);
+    return hat_check_launch();
+}
+
+template <typename T, int WAVES, int PT>
+int dispatch_nt(const HatConvDesc& d, size_t lds, hipStream_t s) {
+    switch (d.nt) {
+        case 1: return launch_conv<T, WAVES, PT, 1>(d, lds, s);
+        case 4: return launch_conv<T, WAVES, PT, 4>(d, lds, s);
+        case 9: return launch_conv<T, WAVES, PT, 9>(d, lds, s);
+        case 12: return launch_conv<T, WAVES, PT, 12>(d, lds, s);
+        default: return HAT_EINVAL;
+    }
+}
+
+template <typename T>
+int dispatch_tile(const HatConvDesc& d, TileCfg tc, size_t lds, hipStream_t s) {
+    if (tc.waves == 8 && tc.pt == 2) return dispatch_nt<T, 8, 2>(d, lds, s);
+    if (tc.waves == 4 && tc.pt == 2) return dispatch_nt<T, 4, 2>(d, lds, s);
+    return dispatch_nt<T, 4, 1>(d, lds, s);
+}
+
+int conv_validate(const HatConvDesc& d) {
+    if (!d.x || !d.w || !d.bias || !d.out) return HAT_EINVAL;
+    if (d.B < 1 || d.H < 1 || d.W < 1 || d.Cin < 1) return HAT_EINVAL;
+    if (d.ksize < 1 || (d.ksize & 1) == 0 || d.ksize > 13) return HAT_EINVAL;
+    if (d.dtype != HAT_F32 && d.dtype != HAT_BF16) return HAT_EINVAL;
+    const int kc = d.dtype == HAT_BF16 ? 64 : 32, vec = d.dtype == HAT_BF16 ? 8 : 4;
+    const int cin_p = (d.Cin + 7) & ~7;
+    if (d.Kpad % kc || d.Kpad < d.ksize * d.ksize * cin_p) return HAT_EINVAL;
+    if (d.n_slices < 1 || d.n_store < 1 || d.n_store > d.n_slices * d.nt * 16) return HAT_EINVAL;
+    if (d.x_mode == HAT_X_NHWC_T) {
+        if (d.ldx % vec || d.ldx < cin_p) return HAT_EINVAL;  // 16-byte rows; pad channels up to Cin_p must exist (zeros)
+        if (d.x0 && (d.ldx0 % vec || d.c_split % vec || d.c_split > d.Cin)) return HAT_EINVAL;
+    } else if (d.x_mode == HAT_X_NHWC_F32) {
+        if (d.ldx % 4 || d.Cin % 4 || d.x0) return HAT_EINVAL;
+    } else if (d.x_mode == HAT_X_NCHW_F32_MEAN) {
+        if (d.Cin > 4 || d.x0) return HAT_EINVAL;
+    } else {
+        return HAT_EINVAL;
+    }
+    if (d.out_mode == HAT_O_NCHW_F32) {
+        if (d.n_store > 4 || d.r1 || d.r2) return HAT_EINVAL;
+    } else {
+        if (d.n_store % 4 || d.ldo % 4) return HAT_EINVAL;
+        if (d.out_mode == HAT_O_PIXSHUF_T) {
+            if (d.ps_r < 2 || d.n_store % (d.ps_r * d.ps_r) || (d.n_store / (d.ps_r * d.ps_r)) % 4 || d.r1 || d.r2) return HAT_EINVAL;
+        } else if (d.out_mode != HAT_O_NHWC_T && d.out_mode != HAT_O_NHWC_F32) {
+            return HAT_EINVAL;
+        }
+    }
+    if (d.r1 && d.ldr1 % 4) return HAT_EINVAL;
+    if (d.r2 && (d.ldr2 % 4 || !d.r2scale)) return HAT_EINVAL;
+    return 0;
+}
+
+}  // namespace
+
+extern "C" int hat_conv_tiles(const HatConvDesc* d, int32_t* tiles_out) {
+    if (!d || !tiles_out) return HAT_EINVAL;
+    TileCfg tc; size_t lds;
+    if (!conv_pick(*d, &tc, &lds)) return HAT_ELDS;
+    *tiles_out = ((d->W + 15) / 16) * ((d->H + tc.waves * tc.pt - 1) / (tc.waves * tc.pt));
+    return 0;
+}
+
+extern "C" int hat_conv(const HatConvDesc* dp, void* stream) {
+    if (!dp) return HAT_EINVAL;
+    const HatConvDesc& d = *dp;
+    int rc = conv_validate(d);
+    if (rc) return rc;
+    TileCfg tc; size_t lds;
+    if (!conv_pick(d, &tc, &lds)) return HAT_ELDS;
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    if (d.dtype == HAT_BF16) return dispatch_tile<bf16_t>(d, tc, lds, s);
+    return dispatch_tile<float>(d, tc, lds, s);
+}

@@ -1,0 +1,308 @@
+// hat_misc.hip — the HBM-bound and tiny kernels of the HAT forward on gfx950:
+// LayerNorm (+ESC global-average-pool partials), ESC per-sample weights, ECA scale,
+// depthwise-3x3 + gate.  Contracts: include/hat_mi355x.h.
+#include "hat_common.h"
+
+namespace {
+
+constexpr int LN_BLOCKS = 1024;  // fixed grid.x: the gap partial layout [B][LN_BLOCKS][16] is deterministic
+
+// One pixel per 16 lanes; lane j owns channels 4j + 64v (float4 each), v < NV  =>  every wave
+// instruction reads 4 pixels x 256 contiguous bytes.  Two-pass statistics in registers.
+template <typename OutT, int NV>
+__global__ __launch_bounds__(256) void ln_kernel(const float* __restrict__ x, OutT* __restrict__ y,
+                                                 const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                 float* __restrict__ gap_partial, long npix, int C, int ldy, int gap_c) {
+    __shared__ float red[16][16];
+    const int tid = threadIdx.x, j = tid & 15, grp = tid >> 4;
+    const int b = blockIdx.y;
+    const float* xb = x + (size_t)b * npix * C;
+    OutT* yb = y + (size_t)b * npix * ldy;
+    f32x4 gm[NV], bt[NV];
+#pragma unroll
+    for (int v = 0; v < NV; ++v) {
+        const int c = 4 * j + 64 * v;
+        gm[v] = f32x4{0.f, 0.f, 0.f, 0.f};
+        bt[v] = gm[v];
+        if (c < C) {
+            gm[v] = *reinterpret_cast<const f32x4*>(gamma + c);
+            bt[v] = *reinterpret_cast<const f32x4*>(beta + c);
+        }
+    }
+    f32x4 gsum = {0.f, 0.f, 0.f, 0.f};
+    const float invC = 1.0f / (float)C;
+    for (long p0 = (long)blockIdx.x * 16; p0 < npix; p0 += (long)gridDim.x * 16) {
+        const long p = p0 + grp;
+        const bool pv = p < npix;
+        f32x4 xv[NV];
+        float s = 0.f;
+#pragma unroll
+        for (int v = 0; v < NV; ++v) {
+            const int c = 4 * j + 64 * v;
+            xv[v] = f32x4{0.f, 0.f, 0.f, 0.f};
+            if (pv && c < C) xv[v] = *reinterpret_cast<const f32x4*>(xb + (size_t)p * C + c);
+            s += (xv[v][0] + xv[v][1]) + (xv[v][2] + xv[v][3]);
+        }
+        s += __shfl_xor(s, 1); s += __shfl_xor(s, 2); s += __shfl_xor(s, 4); s += __shfl_xor(s, 8);
+        const float mean = s * invC;
+        float q = 0.f;
+#pragma unroll
+        for (int v = 0; v < NV; ++v) {
+            const int c = 4 * j + 64 * v;
+            if (c < C) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) { const float dlt = xv[v][r] - mean; q += dlt * dlt; }
+            }
+        }
+        q += __shfl_xor(q, 1); q += __shfl_xor(q, 2); q += __shfl_xor(q, 4); q += __shfl_xor(q, 8);
+        const float rstd = 1.0f / sqrtf(q * invC + 1e-5f);
+#pragma unroll
+        for (int v = 0; v < NV; ++v) {
+            const int c = 4 * j + 64 * v;
+            if (pv && c < C) {
+                f32x4 o;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) o[r] = (xv[v][r] - mean) * rstd * gm[v][r] + bt[v][r];
+                Vec4<OutT>::store(yb + (size_t)p * ldy + c, o);
+                if (v == 0 && c < gap_c) gsum += o;
+            }
+        }
+    }
+    if (gap_partial != nullptr) {
+        // lanes j < 4 hold channels 4j..4j+3 (< 16): fixed-order reduction over the 16 pixel groups
+        if (j < 4) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) red[grp][4 * j + r] = gsum[r];
+        }
+        __syncthreads();
+        if (tid < 16) {
+            float s = 0.f;
+#pragma unroll
+            for (int k = 0; k < 16; ++k) s += red[k][tid];
+            gap_partial[((size_t)b * gridDim.x + blockIdx.x) * 16 + tid] = tid < gap_c ? s : 0.f;
+        }
+    }
+}
+
+template <typename OutT>
+int launch_ln(const float* x, void* y, const float* gamma, const float* beta, float* gap, int B, long npix, int C,
+              int ldy, int gap_c, hipStream_t s) {
+    dim3 grid(LN_BLOCKS, B), block(256);
+    const int nv = (C + 63) / 64;
+    OutT* yo = reinterpret_cast<OutT*>(y);
+    switch (nv) {
+        case 1: hipLaunchKernelGGL((ln_kernel<OutT, 1>), grid, block, 0, s, x, yo, gamma, beta, gap, npix, C, ldy, gap_c); break;
+        case 2: hipLaunchKernelGGL((ln_kernel<OutT, 2>), grid, block, 0, s, x, yo, gamma, beta, gap, npix, C, ldy, gap_c); break;
+        case 3: hipLaunchKernelGGL((ln_kernel<OutT, 3>), grid, block, 0, s, x, yo, gamma, beta, gap, npix, C, ldy, gap_c); break;
+        case 4: hipLaunchKernelGGL((ln_kernel<OutT, 4>), grid, block, 0, s, x, yo, gamma, beta, gap, npix, C, ldy, gap_c); break;
+        default: return HAT_EUNSUPPORTED;
+    }
+    return hat_check_launch();
+}
+
+// ---------------------------------------------------------------------------------------------
+// ESC per-sample weights: one block per (output channel co, sample b).
+// ---------------------------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(256) void esc_weights_kernel(const float* __restrict__ gap_partial, int nblk, float inv_npix,
+                                                          const float* __restrict__ w1, const float* __restrict__ b1,
+                                                          const float* __restrict__ w2, const float* __restrict__ b2,
+                                                          const float* __restrict__ plk, T* __restrict__ w_out,
+                                                          int pdim, int ksize, int Kpad) {
+    __shared__ float part[16][16];
+    __shared__ float pmean[16];
+    __shared__ float hid[8];
+    __shared__ float dk[9];
+    const int tid = threadIdx.x, co = blockIdx.x, b = blockIdx.y;
+    if (co >= pdim) {  // rows pdim..15 of the 16-row MFMA tile are zero
+        T* z = w_out + ((size_t)b * 16 + co) * Kpad;
+        for (int k = tid; k < Kpad; k += 256) z[k] = to_T<T>(0.f);
+        return;
+    }
+    {
+        const int ci = tid & 15, pp = tid >> 4;
+        float s = 0.f;
+        for (int k = pp; k < nblk; k += 16) s += gap_partial[((size_t)b * nblk + k) * 16 + ci];
+        part[pp][ci] = s;
+    }
+    __syncthreads();
+    if (tid < 16) {
+        float s = 0.f;
+#pragma unroll
+        for (int k = 0; k < 16; ++k) s += part[k][tid];
+        pmean[tid] = s * inv_npix;
+    }
+    __syncthreads();
+    const int hdim = pdim / 2;
+    if (tid < hdim) {
+        float s = b1[tid];
+        for (int ci = 0; ci < pdim; ++ci) s += w1[tid * pdim + ci] * pmean[ci];
+        hid[tid] = gelu_erf(s);
+    }
+    __syncthreads();
+    if (tid < 9) {
+        const int t = co * 9 + tid;
+        float s = b2[t];
+        for (int m = 0; m < hdim; ++m) s += w2[t * hdim + m] * hid[m];
+        dk[tid] = s;
+    }
+    __syncthreads();
+    const int cin_p = (pdim + 7) & ~7;
+    const int ctr = ksize / 2;
+    const float* src = plk + (size_t)co * Kpad;
+    T* dst = w_out + ((size_t)b * 16 + co) * Kpad;
+    for (int k = tid; k < Kpad; k += 256) {
+        float v = src[k];
+        const int tap = k / cin_p, ci = k - tap * cin_p;
+        if (ci == co && tap < ksize * ksize) {
+            const int dy = tap / ksize - ctr, dx = tap % ksize - ctr;
+            if (dy >= -1 && dy <= 1 && dx >= -1 && dx <= 1) v += dk[(dy + 1) * 3 + (dx + 1)];
+        }
+        dst[k] = to_T<T>(v);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// ECA: two-stage deterministic reduction of hat_conv's per-tile column sums, conv1d, sigmoid.
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void eca_reduce_kernel(const float* __restrict__ colsum, int tiles, int ldc,
+                                                         float* __restrict__ tmp) {
+    const int c = threadIdx.x, part = blockIdx.x, b = blockIdx.y;
+    if (c >= ldc) return;
+    const int per = (tiles + 31) / 32;
+    const int t0 = part * per, t1 = min(tiles, t0 + per);
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+    int t = t0;
+    for (; t + 3 < t1; t += 4) {
+        s0 += colsum[((size_t)b * tiles + t) * ldc + c];
+        s1 += colsum[((size_t)b * tiles + t + 1) * ldc + c];
+        s2 += colsum[((size_t)b * tiles + t + 2) * ldc + c];
+        s3 += colsum[((size_t)b * tiles + t + 3) * ldc + c];
+    }
+    for (; t < t1; ++t) s0 += colsum[((size_t)b * tiles + t) * ldc + c];
+    tmp[((size_t)b * 32 + part) * ldc + c] = (s0 + s1) + (s2 + s3);
+}
+
+__global__ __launch_bounds__(256) void eca_scale_kernel(const float* __restrict__ tmp, int ldc, float inv_npix,
+                                                        const float* __restrict__ wk, int k, float conv_scale,
+                                                        float* __restrict__ scale, int C) {
+    __shared__ float mean[256];
+    const int c = threadIdx.x, b = blockIdx.x;
+    float s = 0.f;
+    if (c < C) {
+        for (int p = 0; p < 32; ++p) s += tmp[((size_t)b * 32 + p) * ldc + c];
+    }
+    mean[c] = s * inv_npix;
+    __syncthreads();
+    if (c < C) {
+        float e = 0.f;
+        for (int j = 0; j < k; ++j) {
+            const int cc = c + j - k / 2;
+            if (cc >= 0 && cc < C) e += wk[j] * mean[cc];
+        }
+        scale[(size_t)b * ldc + c] = conv_scale / (1.0f + expf(-e));
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// depthwise 3x3 + bias on 2*hid channels, then a * silu(g).  4 channels per thread.
+// ---------------------------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(256) void dwgate_kernel(const T* __restrict__ u, const float* __restrict__ wdw,
+                                                     const float* __restrict__ bdw, T* __restrict__ out, int B, int H, int W,
+                                                     int hid, int ldu, int ldo) {
+    const int gpp = hid / 4;
+    const size_t total = (size_t)B * H * W * gpp;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+        const size_t pix = i / gpp;
+        const int c = (int)(i - pix * gpp) * 4;
+        const int x = (int)(pix % W);
+        const int y = (int)((pix / W) % H);
+        f32x4 a = *reinterpret_cast<const f32x4*>(bdw + c);
+        f32x4 gt = *reinterpret_cast<const f32x4*>(bdw + hid + c);
+#pragma unroll
+        for (int dy = -1; dy <= 1; ++dy) {
+            const int yy = y + dy;
+            if (yy < 0 || yy >= H) continue;
+#pragma unroll
+            for (int dx = -1; dx <= 1; ++dx) {
+                const int xx = x + dx;
+                if (xx < 0 || xx >= W) continue;
+                const T* up = u + (size_t)((long)pix + (long)dy * W + dx) * ldu;
+                const int tap = (dy + 1) * 3 + (dx + 1);
+                a += Vec4<T>::load(up + c) * *reinterpret_cast<const f32x4*>(wdw + (size_t)tap * 2 * hid + c);
+                gt += Vec4<T>::load(up + hid + c) * *reinterpret_cast<const f32x4*>(wdw + (size_t)tap * 2 * hid + hid + c);
+            }
+        }
+        f32x4 o;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) o[r] = a[r] * (gt[r] / (1.0f + expf(-gt[r])));
+        Vec4<T>::store(out + pix * ldo + c, o);
+    }
+}
+
+}  // namespace
+
+extern "C" int hat_layernorm_blocks(void) { return LN_BLOCKS; }
+
+extern "C" int hat_layernorm(const float* x, void* y, const float* gamma, const float* beta, float* gap_partial,
+                             int32_t B, int64_t npix, int32_t C, int32_t ldy, int32_t out_f32, int32_t gap_c,
+                             int32_t dtype, void* stream) {
+    if (!x || !y || !gamma || !beta || B < 1 || npix < 1 || C < 4 || C % 4 || C > 256 || ldy < C || ldy % 4) return HAT_EINVAL;
+    if (gap_c < 0 || gap_c > 16 || gap_c % 4 || (gap_c > 0 && !gap_partial)) return HAT_EINVAL;
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    float* gp = gap_c > 0 ? gap_partial : nullptr;
+    if (out_f32 || dtype == HAT_F32) return launch_ln<float>(x, y, gamma, beta, gp, B, npix, C, ldy, gap_c, s);
+    if (dtype == HAT_BF16) return launch_ln<bf16_t>(x, y, gamma, beta, gp, B, npix, C, ldy, gap_c, s);
+    return HAT_EINVAL;
+}
+
+extern "C" int hat_esc_weights(const float* gap_partial, int32_t nblk, int64_t npix, const float* w1, const float* b1,
+                               const float* w2, const float* b2, const float* plk_packed, void* w_out, int32_t B,
+                               int32_t pdim, int32_t ksize, int32_t Kpad, int32_t dtype, void* stream) {
+    if (!gap_partial || !w1 || !b1 || !w2 || !b2 || !plk_packed || !w_out) return HAT_EINVAL;
+    if (pdim < 2 || pdim > 16 || pdim % 4 || ksize < 3 || (ksize & 1) == 0 || B < 1 || nblk < 1) return HAT_EINVAL;
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    dim3 grid(16, B), block(256);
+    const float inv = 1.0f / (float)npix;
+    if (dtype == HAT_BF16)
+        hipLaunchKernelGGL(esc_weights_kernel<bf16_t>, grid, block, 0, s, gap_partial, nblk, inv, w1, b1, w2, b2, plk_packed,
+                           reinterpret_cast<bf16_t*>(w_out), pdim, ksize, Kpad);
+    else if (dtype == HAT_F32)
+        hipLaunchKernelGGL(esc_weights_kernel<float>, grid, block, 0, s, gap_partial, nblk, inv, w1, b1, w2, b2, plk_packed,
+                           reinterpret_cast<float*>(w_out), pdim, ksize, Kpad);
+    else
+        return HAT_EINVAL;
+    return hat_check_launch();
+}
+
+extern "C" int hat_eca_scale(const float* colsum, int32_t tiles, int32_t ldc, int64_t npix, const float* wk, int32_t k,
+                             float conv_scale, float* tmp, float* scale, int32_t B, int32_t C, void* stream) {
+    if (!colsum || !wk || !tmp || !scale || tiles < 1 || ldc < C || ldc > 256 || C < 1 || k < 1 || (k & 1) == 0 || B < 1) return HAT_EINVAL;
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    hipLaunchKernelGGL(eca_reduce_kernel, dim3(32, B), dim3(256), 0, s, colsum, tiles, ldc, tmp);
+    int rc = hat_check_launch();
+    if (rc) return rc;
+    hipLaunchKernelGGL(eca_scale_kernel, dim3(B), dim3(256), 0, s, tmp, ldc, 1.0f / (float)npix, wk, k, conv_scale, scale, C);
+    return hat_check_launch();
+}
+
+extern "C" int hat_dwconv_gate(const void* u, const float* wdw, const float* bdw, void* out, int32_t B, int32_t H,
+                               int32_t W, int32_t hid, int32_t ldu, int32_t ldo, int32_t dtype, void* stream) {
+    if (!u || !wdw || !bdw || !out || B < 1 || H < 1 || W < 1 || hid < 4 || hid % 4 || ldu < 2 * hid || ldu % 4 || ldo < hid || ldo % 4) return HAT_EINVAL;
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    const size_t total = (size_t)B * H * W * (hid / 4);
+    const int blocks = (int)((total + 255) / 256 < 8192 ? (total + 255) / 256 : 8192);
+    if (dtype == HAT_BF16)
+        hipLaunchKernelGGL(dwgate_kernel<bf16_t>, dim3(blocks), dim3(256), 0, s, reinterpret_cast<const bf16_t*>(u), wdw, bdw,
+                           reinterpret_cast<bf16_t*>(out), B, H, W, hid, ldu, ldo);
+    else if (dtype == HAT_F32)
+        hipLaunchKernelGGL(dwgate_kernel<float>, dim3(blocks), dim3(256), 0, s, reinterpret_cast<const float*>(u), wdw, bdw,
+                           reinterpret_cast<float*>(out), B, H, W, hid, ldu, ldo);
+    else
+        return HAT_EINVAL;
+    return hat_check_launch();
+}
+
+extern "C" int hat_abi_version(void) { return HAT_ABI_VERSION; }
+extern "C" const char* hat_target_arch(void) { return "gfx950"; }

@@ -1,0 +1,292 @@
+"""HATEngine — host-side orchestration of the HIP kernels for one HAT network.
+
+Holds the packed weights (per storage dtype) and a per-shape workspace in HBM, and enqueues the
+kernel sequence of `HAT.forward` (reference: hat/archs/hat_arch.py:848-859 and the blocks it
+calls; op-by-op map in SURVEY.md App. A) on the current stream.  Nothing here computes on the
+CPU or through torch ops: torch only allocates device buffers and packs weights at load time.
+
+Data layout in HBM (B = batch, N = H*W pixels, C = embed_dim):
+  residual stream      tA, tB : fp32 (B, N, C)  two buffers: tA = RHAG input/output, tB = working copy
+  shallow feature      f0     : fp32 (B, N, C)
+  MFMA operands        n, c2, q, ao : T (B, N, ld(C));  u : T (B, N, ld(4C));  g, kv : T (B, N, ld(2C))
+                       c1 : T (B, N, ld(C/cr));  y16 : T (B, N, pdim)       ld(x) = round_up(x, 8)
+  upsampler            fb : T (B, N, 64);  up_i : T (B, r^2i N, 64);  output y : fp32 (B, 3, sH, sW) NCHW
+T = bf16 (performance path) or fp32 (exact-fp32 parity path).
+"""
+from __future__ import annotations
+
+import math
+from typing import Dict, Optional
+
+import torch
+
+from . import ops
+from .ops import (ACT_GELU, ACT_LRELU, ACT_NONE, O_NCHW_F32, O_NHWC_F32, O_NHWC_T, O_PIXSHUF_T, X_NCHW_F32_MEAN,
+                  X_NHWC_F32, X_NHWC_T)
+
+RGB_MEAN = (0.4488, 0.4371, 0.4040)  # hat_arch.py:659
+
+
+def _r8(x: int) -> int:
+    return (x + 7) // 8 * 8
+
+
+def _r4(x: int) -> int:
+    return (x + 3) // 4 * 4
+
+
+class _ESC:
+    """Packed parameters of one ConvAttnWrapper (esc_arch.py:136-145) + its large-kernel filter."""
+
+    def __init__(self, sd, core: str, plk_key: str, pdim: int, ksize: int, C: int, dtype: int, dev):
+        f32 = dict(dtype=torch.float32, device=dev)
+        self.pdim, self.ksize = pdim, ksize
+        self.w1 = sd[core + ".plk.dwc_proj.1.weight"].detach().reshape(pdim // 2, pdim).to(**f32).contiguous()
+        self.b1 = sd[core + ".plk.dwc_proj.1.bias"].detach().to(**f32).contiguous()
+        self.w2 = sd[core + ".plk.dwc_proj.3.weight"].detach().reshape(pdim * 9, pdim // 2).to(**f32).contiguous()
+        self.b2 = sd[core + ".plk.dwc_proj.3.bias"].detach().to(**f32).contiguous()
+        # static large-kernel filter packed in fp32 [16][Kpad]; hat_esc_weights adds the dynamic
+        # depthwise 3x3 on the diagonal of the central taps and casts to T per forward
+        lk = ops.pack_conv_weight(sd[plk_key], None, ops.HAT_F32, dev, nt=1)
+        kc = ops.KC[dtype]
+        self.kpad = -(-(ksize * ksize * _r8(pdim)) // kc) * kc
+        plk = torch.zeros(16, self.kpad, **f32)
+        plk[:, :min(self.kpad, lk.kpad)] = lk.w[:16, :min(self.kpad, lk.kpad)]
+        self.plk = plk.contiguous()
+        self.zero_bias = torch.zeros(16, **f32)
+        self.aggr = ops.pack_conv_weight(sd[core + ".aggr.weight"], sd[core + ".aggr.bias"], dtype, dev)
+
+
+class HATEngine:
+    def __init__(self, cfg: dict, state_dict: Dict[str, torch.Tensor], device, dtype: str = "bf16"):
+        if cfg.get("upsampler") != "pixelshuffle":
+            raise NotImplementedError("only upsampler='pixelshuffle' is on the hot path (all shipped test YAMLs)")
+        if cfg.get("resi_connection", "1conv") != "1conv":
+            raise NotImplementedError("resi_connection='identity' is not implemented (no shipped config uses it)")
+        if cfg.get("ape", False):
+            raise NotImplementedError("ape=True is not implemented (no shipped config uses it)")
+        self.cfg = cfg
+        self.dev = torch.device(device)
+        if self.dev.type != "cuda":
+            raise RuntimeError("HATEngine needs a GPU device: there is no CPU path")
+        self.dtype = ops.DTYPE_CODE[dtype]
+        self.tdt = ops.TORCH_DTYPE[self.dtype]
+        self.C = cfg["embed_dim"]
+        self.ws = cfg["window_size"]
+        self.wse = self.ws + int(cfg["overlap_ratio"] * self.ws)
+        self.scale = cfg["upscale"]
+        self._ws_cache = {}
+        ops._lib.load()
+        self._pack(state_dict)
+
+    # ------------------------------------------------------------------------------------------
+    def _pack(self, sd):
+        cfg, dt, dev, C = self.cfg, self.dtype, self.dev, self.C
+        f32 = dict(dtype=torch.float32, device=dev)
+        P = lambda w, b=None, **kw: ops.pack_conv_weight(sd[w], None if b is None else sd[b], dt, dev, **kw)
+        vec = lambda k: sd[k].detach().to(**f32).contiguous()
+        self.conv_first = P("conv_first.weight", "conv_first.bias")
+        self.pe_norm = (vec("patch_embed.norm.weight"), vec("patch_embed.norm.bias")) if cfg.get("patch_norm", True) else None
+        self.layers = []
+        ws, wse = self.ws, self.wse
+        M = ws + wse - 1
+        shift = (ws - wse + 1 - (ws - 1)) * (M + 1)  # rotated index i' -> reference index rpi = i' + shift (may be < 0)
+        rot = (torch.arange(M * M) + shift) % (M * M)  # negative-index wraparound of hat_arch.py:378
+        for g, (depth, heads) in enumerate(zip(cfg["depths"], cfg["num_heads"])):
+            L = {"heads": heads, "habs": []}
+            for i in range(depth):
+                p = f"layers.{g}.residual_group.blocks.{i}"
+                hb = {
+                    "n1": (vec(p + ".norm1.weight"), vec(p + ".norm1.bias")),
+                    "n2": (vec(p + ".norm2.weight"), vec(p + ".norm2.bias")),
+                    "esc": _ESC(sd, p + ".esc_attn.core", p + ".esc_attn.plk_filter", cfg["esc_pdim"], cfg["esc_kernel"], C, dt, dev),
+                    "cab0": P(p + ".conv_block.cab.0.weight", p + ".conv_block.cab.0.bias"),
+                    "cab2": P(p + ".conv_block.cab.2.weight", p + ".conv_block.cab.2.bias"),
+                    "eca_w": vec(p + ".conv_block.cab.3.conv.weight").reshape(-1),
+                    "fc1": P(p + ".mlp.fc1.weight", p + ".mlp.fc1.bias"),
+                    "fc2": P(p + ".mlp.fc2.weight", p + ".mlp.fc2.bias"),
+                }
+                hid2 = sd[p + ".mlp.dw.weight"].shape[0]
+                hb["dw_w"] = sd[p + ".mlp.dw.weight"].detach().to(**f32).reshape(hid2, 9).t().contiguous()  # [9][2*hid]
+                hb["dw_b"] = vec(p + ".mlp.dw.bias")
+                L["habs"].append(hb)
+            p = f"layers.{g}.residual_group.overlap_attn"
+            d = C // heads
+            qscale = cfg.get("qk_scale") or d ** -0.5
+            table = sd[p + ".relative_position_bias_table"].detach().to(torch.float32).cpu()  # (M*M, heads)
+            oc = {
+                "n1": (vec(p + ".norm1.weight"), vec(p + ".norm1.bias")),
+                "n2": (vec(p + ".norm2.weight"), vec(p + ".norm2.bias")),
+                # q * scale (hat_arch.py:375) is folded into the projection
+                "q": ops.pack_conv_weight(sd[p + ".q_proj.weight"], sd.get(p + ".q_proj.bias"), dt, dev, scale=qscale),
+                "kv": ops.pack_conv_weight(sd[p + ".kv_proj.weight"], sd.get(p + ".kv_proj.bias"), dt, dev),
+                "proj": P(p + ".proj.weight", p + ".proj.bias"),
+                "mlp0": P(p + ".mlp.0.weight", p + ".mlp.0.bias"),
+                "mlp2": P(p + ".mlp.2.weight", p + ".mlp.2.bias"),
+                "bias_rot": table[rot].t().contiguous().to(dev),  # [heads][M*M]
+            }
+            if cfg.get("ocab_esc_enable", False):
+                oc["esc"] = _ESC(sd, p + ".esc_core", p + ".esc_plk", cfg["ocab_esc_pdim"], cfg["ocab_esc_kernel"], C, dt, dev)
+            L["ocab"] = oc
+            L["conv"] = P(f"layers.{g}.conv.weight", f"layers.{g}.conv.bias")
+            self.layers.append(L)
+        self.norm = (vec("norm.weight"), vec("norm.bias"))
+        self.conv_after_body = P("conv_after_body.weight", "conv_after_body.bias")
+        self.conv_before_up = P("conv_before_upsample.0.weight", "conv_before_upsample.0.bias")
+        self.ups = []
+        s = self.scale
+        if s & (s - 1) == 0:
+            for i in range(int(math.log2(s))):
+                self.ups.append((self._pack_ps(sd, f"upsample.{2 * i}", 2), 2))
+        elif s == 3:
+            self.ups.append((self._pack_ps(sd, "upsample.0", 3), 3))
+        else:
+            raise ValueError(f"scale {s} is not supported. Supported scales: 2^n and 3.")
+        self.conv_last = P("conv_last.weight", "conv_last.bias")
+
+    def _pack_ps(self, sd, key, r):
+        """Conv feeding nn.PixelShuffle(r) (hat_arch.py:598-602): output channel c*r^2 + i*r + j is stored
+        as packed row (i*r + j)*Cps + c so one lane's 4 consecutive channels land in ONE output pixel."""
+        w = sd[key + ".weight"]
+        o = w.shape[0]
+        cps = o // (r * r)
+        n = torch.arange(o)
+        perm = (n % cps) * (r * r) + n // cps  # packed row n' = ij*cps + c  <-  original channel c*r^2 + ij
+        return ops.pack_conv_weight(w, sd[key + ".bias"], self.dtype, self.dev, out_perm=perm)
+
+    # ------------------------------------------------------------------------------------------
+    def _workspace(self, B, H, W):
+        key = (B, H, W)
+        ws = self._ws_cache.get(key)
+        if ws is not None:
+            return ws
+        self._ws_cache.clear()  # one shape at a time: frames are big
+        C, dev, T = self.C, self.dev, self.tdt
+        N = H * W
+        mid = self.layers[0]["habs"][0]["cab0"].nout if self.layers and self.layers[0]["habs"] else 8
+        hid2 = self.layers[0]["habs"][0]["fc1"].nout if self.layers and self.layers[0]["habs"] else 4 * C
+        z = lambda *shape, dtype=T: torch.zeros(*shape, dtype=dtype, device=dev)
+        f = torch.float32
+        w = {
+            "f0": z(B, N, C, dtype=f), "tA": z(B, N, C, dtype=f), "tB": z(B, N, C, dtype=f),
+            "n": z(B, N, _r8(C)), "c1": z(B, N, _r8(mid)), "c2": z(B, N, _r8(C)),
+            "y16": z(B, N, 16), "u": z(B, N, _r8(max(hid2, 2 * C))), "g": z(B, N, _r8(max(hid2 // 2, 2 * C))),
+            "q": z(B, N, _r8(C)), "kv": z(B, N, _r8(2 * C)), "ao": z(B, N, _r8(C)),
+            "fb": z(B, N, 64),
+            "gap": z(B, ops.layernorm_blocks(), 16, dtype=f),
+            "scale": z(B, 256, dtype=f), "eca_tmp": z(B, 32, 256, dtype=f),
+        }
+        esc0 = self.layers[0]["habs"][0]["esc"] if self.layers and self.layers[0]["habs"] else None
+        kpad = max([esc0.kpad if esc0 else 0] + [L["ocab"]["esc"].kpad for L in self.layers if "esc" in L["ocab"]])
+        w["weff"] = z(B, 16, max(kpad, 64))
+        if any("esc" in L["ocab"] for L in self.layers):
+            w["yesc"] = z(B, N, _r8(C))
+        cab2 = self.layers[0]["habs"][0]["cab2"] if self.layers and self.layers[0]["habs"] else None
+        if cab2 is not None:
+            tiles = ops.conv_tiles(cab2, H, W, self.dtype)
+            w["tiles"] = tiles
+            w["colsum"] = z(B, tiles, cab2.npad, dtype=f)
+        h, wd = H, W
+        w["ups"] = []
+        for _, r in self.ups:
+            h, wd = h * r, wd * r
+            w["ups"].append(z(B, h * wd, 64))
+        self._ws_cache[key] = w
+        return w
+
+    # ------------------------------------------------------------------------------------------
+    def _esc_lk(self, esc: _ESC, w, n, B, H, W):
+        """ESC large-kernel + dynamic depthwise conv on the first pdim channels of `n` -> w['y16']."""
+        dt, C = self.dtype, self.C
+        N = H * W
+        ops.esc_weights(w["gap"], ops.layernorm_blocks(), N, esc.w1, esc.b1, esc.w2, esc.b2, esc.plk, w["weff"], B=B,
+                        pdim=esc.pdim, ksize=esc.ksize, kpad=esc.kpad, dtype=dt)
+        pw = ops.PackedConv(w["weff"], esc.zero_bias, esc.ksize, esc.pdim, esc.kpad, 1, 1, esc.pdim,
+                            w_bstride=16 * esc.kpad)
+        ops.conv(pw, n, w["y16"], B=B, H=H, W=W, dtype=dt, ldx=_r8(C), ldo=16, n_store=_r4(esc.pdim))
+
+    def forward(self, x: torch.Tensor) -> torch.Tensor:
+        if not x.is_cuda:
+            raise RuntimeError("HAT forward needs a device tensor: the HIP path is the only path")
+        if x.dim() != 4 or x.shape[1] != self.cfg["in_chans"]:
+            raise RuntimeError(f"expected (B,{self.cfg['in_chans']},H,W), got {tuple(x.shape)}")
+        B, _, H, W = x.shape
+        ws = self.ws
+        if H % ws or W % ws:  # the reference raises from calculate_mask's view (hat_arch.py:815), SURVEY F4
+            raise RuntimeError(f"input size ({H},{W}) is not a multiple of window_size {ws}")
+        x = x.to(torch.float32).contiguous()
+        cfg, dt, C = self.cfg, self.dtype, self.C
+        N, ldc = H * W, _r8(C)
+        w = self._workspace(B, H, W)
+        s = self.scale
+        y = torch.empty(B, cfg["in_chans"], H * s, W * s, dtype=torch.float32, device=self.dev)
+        mean = RGB_MEAN if cfg["in_chans"] == 3 else (0.0,) * 4
+        r = float(cfg.get("img_range", 1.0))
+        geo = dict(B=B, H=H, W=W, dtype=dt)
+        ln = lambda src, dst, gb, out_f32=False, gap_c=0: ops.layernorm(
+            src, dst, gb[0], gb[1], B=B, npix=N, C_=C, ldy=(C if out_f32 else ldc), out_f32=out_f32, dtype=dt,
+            gap=(w["gap"] if gap_c else None), gap_c=gap_c)
+
+        # (x - mean) * img_range ; conv_first                                           :849-853
+        ops.conv(self.conv_first, x, w["f0"], **geo, ldx=0, ldo=C, x_mode=X_NCHW_F32_MEAN, out_mode=O_NHWC_F32,
+                 in_scale=r, mean=mean)
+        tA, tB = w["tA"], w["tB"]
+        if self.pe_norm is not None:  # patch_embed + LN                                 :836
+            ln(w["f0"], tA, self.pe_norm, out_f32=True)
+        else:
+            tA.copy_(w["f0"])
+        for L in self.layers:
+            for i, hb in enumerate(L["habs"]):  # HAB                                     :217-238
+                tin = tA if i == 0 else tB
+                esc = hb["esc"]
+                ln(tin, w["n"], hb["n1"], gap_c=esc.pdim)
+                mid = hb["cab0"].nout
+                ops.conv(hb["cab0"], w["n"], w["c1"], **geo, ldx=ldc, ldo=_r8(mid), act=ACT_GELU, n_store=_r4(mid))
+                ops.conv(hb["cab2"], w["c1"], w["c2"], **geo, ldx=_r8(mid), ldo=ldc, colsum=w["colsum"])
+                ops.eca_scale(w["colsum"], w["tiles"], hb["cab2"].npad, N, hb["eca_w"], hb["eca_w"].numel(),
+                              float(cfg["conv_scale"]), w["eca_tmp"], w["scale"], B=B, C_=C)
+                self._esc_lk(esc, w, w["n"], B, H, W)
+                # t = t + aggr(cat(y16, n[pdim:])) + conv_scale * eca * c2                :236
+                ops.conv(esc.aggr, w["n"], tB, **geo, ldx=ldc, ldo=C, out_mode=O_NHWC_F32, x0=w["y16"], c_split=esc.pdim,
+                         ldx0=16, r1=tin, ldr1=C, r2=w["c2"], ldr2=ldc, r2scale=w["scale"], r2scale_bstride=hb["cab2"].npad)
+                ln(tB, w["n"], hb["n2"])
+                hid2 = hb["fc1"].nout
+                ops.conv(hb["fc1"], w["n"], w["u"], **geo, ldx=ldc, ldo=w["u"].shape[2])
+                ops.dwconv_gate(w["u"], hb["dw_w"], hb["dw_b"], w["g"], B=B, H=H, W=W, hid=hid2 // 2, ldu=w["u"].shape[2],
+                                ldo=w["g"].shape[2], dtype=dt)
+                ops.conv(hb["fc2"], w["g"], tB, **geo, ldx=w["g"].shape[2], ldo=C, out_mode=O_NHWC_F32, r1=tB, ldr1=C)
+            t = tB if L["habs"] else tA
+            oc = L["ocab"]  # OCAB                                                         :326-393
+            esc = oc.get("esc")
+            ln(t, w["n"], oc["n1"], gap_c=(esc.pdim if esc else 0))
+            kv_src = w["n"]
+            if esc is not None:  # K/V from ESC(LN(x))                                     :336-344
+                self._esc_lk(esc, w, w["n"], B, H, W)
+                ops.conv(esc.aggr, w["n"], w["yesc"], **geo, ldx=ldc, ldo=ldc, x0=w["y16"], c_split=esc.pdim, ldx0=16)
+                kv_src = w["yesc"]
+            ops.conv(oc["q"], w["n"], w["q"], **geo, ldx=ldc, ldo=ldc)
+            ops.conv(oc["kv"], kv_src, w["kv"], **geo, ldx=ldc, ldo=w["kv"].shape[2])
+            ops.ocab_attention(w["q"], w["kv"], oc["bias_rot"], w["ao"], B=B, H=H, W=W, C_=C, heads=L["heads"], ws=ws,
+                               wse=self.wse, ldq=ldc, ldkv=w["kv"].shape[2], ldo=ldc, dtype=dt)
+            tout = tB if L["habs"] else tA
+            ops.conv(oc["proj"], w["ao"], tout, **geo, ldx=ldc, ldo=C, out_mode=O_NHWC_F32, r1=t, ldr1=C)
+            ln(tout, w["n"], oc["n2"])
+            ops.conv(oc["mlp0"], w["n"], w["g"], **geo, ldx=ldc, ldo=w["g"].shape[2], act=ACT_GELU)
+            ops.conv(oc["mlp2"], w["g"], tout, **geo, ldx=w["g"].shape[2], ldo=C, out_mode=O_NHWC_F32, r1=tout, ldr1=C)
+            # RHAG tail: conv3x3 + group residual                                          :556
+            if tout is tA:  # no HAB in this group: the conv must not read the buffer it writes
+                tB.copy_(tA)
+                tout = tB
+            ops.conv(L["conv"], tout, tA, **geo, ldx=C, ldo=C, x_mode=X_NHWC_F32, out_mode=O_NHWC_F32, r1=tA, ldr1=C)
+        ln(tA, w["n"], self.norm)  # final LN                                             :844
+        # conv_after_body + f0 ; conv_before_upsample + LeakyReLU                          :854-855
+        ops.conv(self.conv_after_body, w["n"], w["c2"], **geo, ldx=ldc, ldo=ldc, r1=w["f0"], ldr1=C)
+        ops.conv(self.conv_before_up, w["c2"], w["fb"], **geo, ldx=ldc, ldo=64, act=ACT_LRELU)
+        src, h, wd = w["fb"], H, W
+        for (pw, rr), dst in zip(self.ups, w["ups"]):  # conv + PixelShuffle                :593-605
+            ops.conv(pw, src, dst, B=B, H=h, W=wd, dtype=dt, ldx=64, ldo=64, out_mode=O_PIXSHUF_T, ps_r=rr)
+            src, h, wd = dst, h * rr, wd * rr
+        # conv_last ; / img_range + mean                                                   :856-858
+        ops.conv(self.conv_last, src, y, B=B, H=h, W=wd, dtype=dt, ldx=64, ldo=0, out_mode=O_NCHW_F32,
+                 out_scale=1.0 / r, mean=mean)
+        return y

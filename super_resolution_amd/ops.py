@@ -1,0 +1,157 @@
+"""Tensor-level wrappers over the C ABI: torch tensors in (device memory, current stream), raw
+pointers out.  PyTorch is plumbing here — allocation and stream ownership — no torch op computes
+anything on the hot path.  Every wrapper raises if the library is missing or a call fails.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Optional
+
+import torch
+
+from . import _lib
+from ._lib import (ACT_GELU, ACT_LRELU, ACT_NONE, HAT_BF16, HAT_F32, O_NCHW_F32, O_NHWC_F32, O_NHWC_T, O_PIXSHUF_T,
+                   X_NCHW_F32_MEAN, X_NHWC_F32, X_NHWC_T, HatConvDesc)
+
+TORCH_DTYPE = {HAT_F32: torch.float32, HAT_BF16: torch.bfloat16}
+DTYPE_CODE = {"f32": HAT_F32, "fp32": HAT_F32, "float32": HAT_F32, "bf16": HAT_BF16, "bfloat16": HAT_BF16}
+KC = {HAT_F32: 32, HAT_BF16: 64}
+
+
+def _ptr(t: Optional[torch.Tensor]) -> Optional[int]:
+    if t is None:
+        return None
+    if not t.is_cuda:
+        raise RuntimeError("HAT HIP ops need device tensors (no CPU path exists)")
+    if not t.is_contiguous():
+        raise RuntimeError("HAT HIP ops need contiguous tensors")
+    return t.data_ptr()
+
+
+def _stream() -> int:
+    return torch.cuda.current_stream().cuda_stream
+
+
+class PackedConv:
+    """Packed weights of one conv/linear layer (see HatConvDesc in include/hat_mi355x.h)."""
+    __slots__ = ("w", "bias", "ksize", "cin", "kpad", "nt", "n_slices", "nout", "w_bstride")
+
+    def __init__(self, w, bias, ksize, cin, kpad, nt, n_slices, nout, w_bstride=0):
+        self.w, self.bias, self.ksize, self.cin, self.kpad = w, bias, ksize, cin, kpad
+        self.nt, self.n_slices, self.nout, self.w_bstride = nt, n_slices, nout, w_bstride
+
+    @property
+    def npad(self):
+        return self.nt * 16 * self.n_slices
+
+
+def choose_nt(nout: int):
+    """n-tiles per slice in {12, 9, 4, 1}: least padded work, weighted by LDS fragment reads per MFMA."""
+    best = None
+    for nt in (12, 9, 4, 1):
+        npad = -(-nout // (16 * nt)) * 16 * nt
+        cost = npad * (nt + 2) / nt
+        if best is None or cost < best[0]:
+            best = (cost, nt, npad // (16 * nt))
+    return best[1], best[2]
+
+
+def pack_conv_weight(weight: torch.Tensor, bias: Optional[torch.Tensor], dtype: int, device, out_perm=None,
+                     scale: float = 1.0, nt: Optional[int] = None) -> PackedConv:
+    """weight (O, I, k, k) [or (O, I) for nn.Linear] -> [Npad][Kpad] with K = tap * Cin_p + ci."""
+    w = weight.detach().to(torch.float32).cpu()
+    if w.dim() == 2:
+        w = w[:, :, None, None]
+    o, i, kh, kw = w.shape
+    assert kh == kw
+    b = torch.zeros(o) if bias is None else bias.detach().to(torch.float32).cpu()
+    if scale != 1.0:
+        w, b = w * scale, b * scale
+    if out_perm is not None:
+        w, b = w[out_perm], b[out_perm]
+    cin_p = (i + 7) // 8 * 8
+    kc = KC[dtype]
+    k = kh * kw * cin_p
+    kpad = -(-k // kc) * kc
+    if nt is None:
+        nt, n_slices = choose_nt(o)
+    else:
+        n_slices = -(-o // (16 * nt))
+    npad = nt * 16 * n_slices
+    wp = torch.zeros(npad, kpad, dtype=torch.float32)
+    wt = torch.zeros(o, kh * kw, cin_p)
+    wt[:, :, :i] = w.permute(0, 2, 3, 1).reshape(o, kh * kw, i)
+    wp[:o, :k] = wt.reshape(o, k)
+    bp = torch.zeros(npad, dtype=torch.float32)
+    bp[:o] = b
+    return PackedConv(wp.to(TORCH_DTYPE[dtype]).to(device).contiguous(), bp.to(device), kh, i, kpad, nt, n_slices, o)
+
+
+def conv(pw: PackedConv, x: torch.Tensor, out: torch.Tensor, *, B: int, H: int, W: int, dtype: int, ldx: int, ldo: int,
+         x_mode: int = X_NHWC_T, out_mode: int = O_NHWC_T, act: int = ACT_NONE, n_store: Optional[int] = None,
+         x0: Optional[torch.Tensor] = None, c_split: int = 0, ldx0: int = 0,
+         r1: Optional[torch.Tensor] = None, ldr1: int = 0, r2: Optional[torch.Tensor] = None, ldr2: int = 0,
+         r2scale: Optional[torch.Tensor] = None, r2scale_bstride: int = 0, colsum: Optional[torch.Tensor] = None,
+         ps_r: int = 0, in_scale: float = 1.0, out_scale: float = 1.0, mean=(0.0, 0.0, 0.0, 0.0), cin: Optional[int] = None):
+    lib = _lib.load()
+    d = HatConvDesc()
+    d.x, d.x0, d.w, d.bias, d.out = _ptr(x), _ptr(x0), _ptr(pw.w), _ptr(pw.bias), _ptr(out)
+    d.r1, d.r2, d.r2scale, d.colsum = _ptr(r1), _ptr(r2), _ptr(r2scale), _ptr(colsum)
+    d.B, d.H, d.W = B, H, W
+    d.Cin, d.ldx, d.x_mode = (pw.cin if cin is None else cin), ldx, x_mode
+    d.c_split, d.ldx0 = c_split, ldx0
+    d.ksize, d.Kpad, d.nt, d.n_slices, d.w_bstride = pw.ksize, pw.kpad, pw.nt, pw.n_slices, pw.w_bstride
+    d.n_store = pw.nout if n_store is None else n_store
+    d.ldo, d.out_mode, d.act = ldo, out_mode, act
+    d.ldr1, d.ldr2, d.r2scale_bstride, d.ps_r = ldr1, ldr2, r2scale_bstride, ps_r
+    d.in_scale, d.out_scale = in_scale, out_scale
+    for i in range(4):
+        d.mean[i] = float(mean[i]) if i < len(mean) else 0.0
+    d.dtype = dtype
+    _lib.check(lib.hat_conv(C.byref(d), _stream()), f"hat_conv(k={pw.ksize}, Cin={d.Cin}, N={pw.nout})")
+
+
+def conv_tiles(pw: PackedConv, H: int, W: int, dtype: int) -> int:
+    lib = _lib.load()
+    d = HatConvDesc()
+    d.B, d.H, d.W, d.Cin, d.ksize, d.nt, d.n_slices, d.dtype = 1, H, W, pw.cin, pw.ksize, pw.nt, pw.n_slices, dtype
+    n = C.c_int32(0)
+    _lib.check(lib.hat_conv_tiles(C.byref(d), C.byref(n)), "hat_conv_tiles")
+    return n.value
+
+
+def layernorm_blocks() -> int:
+    return _lib.load().hat_layernorm_blocks()
+
+
+def layernorm(x: torch.Tensor, y: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, *, B: int, npix: int, C_: int,
+              ldy: int, out_f32: bool, dtype: int, gap: Optional[torch.Tensor] = None, gap_c: int = 0):
+    lib = _lib.load()
+    _lib.check(lib.hat_layernorm(_ptr(x), _ptr(y), _ptr(gamma), _ptr(beta), _ptr(gap), B, npix, C_, ldy, int(out_f32),
+                                 gap_c, dtype, _stream()), "hat_layernorm")
+
+
+def esc_weights(gap: torch.Tensor, nblk: int, npix: int, w1, b1, w2, b2, plk_packed, w_out, *, B: int, pdim: int,
+                ksize: int, kpad: int, dtype: int):
+    lib = _lib.load()
+    _lib.check(lib.hat_esc_weights(_ptr(gap), nblk, npix, _ptr(w1), _ptr(b1), _ptr(w2), _ptr(b2), _ptr(plk_packed),
+                                   _ptr(w_out), B, pdim, ksize, kpad, dtype, _stream()), "hat_esc_weights")
+
+
+def eca_scale(colsum, tiles: int, ldc: int, npix: int, wk, k: int, conv_scale: float, tmp, scale, *, B: int, C_: int):
+    lib = _lib.load()
+    _lib.check(lib.hat_eca_scale(_ptr(colsum), tiles, ldc, npix, _ptr(wk), k, conv_scale, _ptr(tmp), _ptr(scale), B, C_,
+                                 _stream()), "hat_eca_scale")
+
+
+def dwconv_gate(u, wdw, bdw, out, *, B: int, H: int, W: int, hid: int, ldu: int, ldo: int, dtype: int):
+    lib = _lib.load()
+    _lib.check(lib.hat_dwconv_gate(_ptr(u), _ptr(wdw), _ptr(bdw), _ptr(out), B, H, W, hid, ldu, ldo, dtype, _stream()),
+               "hat_dwconv_gate")
+
+
+def ocab_attention(q, kv, bias_rot, out, *, B: int, H: int, W: int, C_: int, heads: int, ws: int, wse: int, ldq: int,
+                   ldkv: int, ldo: int, dtype: int):
+    lib = _lib.load()
+    _lib.check(lib.hat_ocab_attention(_ptr(q), _ptr(kv), _ptr(bias_rot), _ptr(out), B, H, W, C_, heads, ws, wse, ldq,
+                                      ldkv, ldo, dtype, _stream()), "hat_ocab_attention")

@@ -1,0 +1,344 @@
+"""GPU parity tests, per kernel, THROUGH THE C ABI (super_resolution_amd.ops -> libhat_mi355x.so),
+against the CPU oracle / plain torch fp64 restatements of the same op on the same seeded inputs.
+
+Tolerances: HAT_F32 path (exact-fp32 MFMA): max-abs <= 2e-5 * scale (accumulation-order noise only);
+HAT_BF16 path: relative L2 error <= 1.2e-2 and max-abs <= 6e-2 * scale (bf16 operands, fp32 accumulate).
+"""
+import math
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+from oracle import hat_oracle as O
+from super_resolution_amd import synth
+
+pytestmark = pytest.mark.gpu
+
+DT = ["f32", "bf16"]
+
+
+def _dev():
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    return torch.device("cuda:0")
+
+
+def _ops():
+    from super_resolution_amd import ops
+    return ops
+
+
+def _r8(x):
+    return (x + 7) // 8 * 8
+
+
+def to_dev(x_bhwc: torch.Tensor, ld: int, tdt, dev):
+    """(B,H,W,C) float -> device (B, H*W, ld) of dtype tdt with zero pad channels."""
+    b, h, w, c = x_bhwc.shape
+    out = torch.zeros(b, h * w, ld, dtype=tdt, device=dev)
+    out[:, :, :c] = x_bhwc.reshape(b, h * w, c).to(dev).to(tdt)
+    return out
+
+
+def check(got: torch.Tensor, ref: torch.Tensor, dtype: str, what: str, f32_tol=2e-5):
+    got, ref = got.detach().double().cpu(), ref.detach().double().cpu()
+    assert got.shape == ref.shape, (what, got.shape, ref.shape)
+    assert torch.isfinite(got).all(), what + ": non-finite output"
+    scale = max(float(ref.abs().max()), 1e-6)
+    err = float((got - ref).abs().max())
+    rel = float((got - ref).norm() / max(float(ref.norm()), 1e-12))
+    if dtype == "f32":
+        assert err <= f32_tol * max(scale, 1.0), f"{what}: max-abs {err:.3e} (scale {scale:.3g}, rel {rel:.3e})"
+    else:
+        assert rel <= 1.2e-2 and err <= 6e-2 * max(scale, 1.0), f"{what}: rel {rel:.3e} max-abs {err:.3e} (scale {scale:.3g})"
+
+
+def rnd(key, shape, std=1.0):
+    return synth.normal(11, key, shape, std=std)
+
+
+def q(x, dtype):
+    """Round inputs the way the kernel's storage type does, so the oracle sees the same operands."""
+    return x.to(torch.bfloat16).to(torch.float32) if dtype == "bf16" else x
+
+
+# ------------------------------------------------------------------------------------------------
+CONV_CASES = [
+    # name, B, H, W, Cin, Cout, k, act
+    ("lin144", 1, 16, 32, 144, 144, 1, 0),
+    ("fc1_576", 1, 24, 16, 144, 576, 1, 0),
+    ("fc2_288", 2, 16, 16, 288, 144, 1, 1),
+    ("lin180", 1, 16, 24, 180, 180, 1, 0),
+    ("lin360_180", 1, 8, 40, 360, 180, 1, 0),
+    ("lin24", 1, 8, 24, 24, 48, 1, 1),
+    ("cab0_144_6", 1, 32, 16, 144, 6, 3, 1),
+    ("cab2_6_144", 1, 16, 48, 6, 144, 3, 0),
+    ("conv144", 1, 32, 32, 144, 144, 3, 0),
+    ("conv180_60", 1, 16, 16, 180, 60, 3, 1),
+    ("conv180", 2, 16, 16, 180, 180, 3, 0),
+    ("conv_c64", 1, 20, 28, 144, 64, 3, 2),
+    ("lk13", 1, 32, 32, 16, 16, 13, 0),
+    ("lk5", 1, 16, 24, 8, 8, 5, 0),
+    ("small_3x5", 1, 3, 5, 24, 24, 3, 0),
+]
+
+
+@pytest.mark.parametrize("dtype", DT)
+@pytest.mark.parametrize("case", CONV_CASES, ids=[c[0] for c in CONV_CASES])
+def test_conv_plain(case, dtype):
+    name, B, H, W, Cin, Cout, k, act = case
+    dev, ops = _dev(), _ops()
+    dt = ops.DTYPE_CODE[dtype]
+    tdt = ops.TORCH_DTYPE[dt]
+    x = q(rnd(name + "x", (B, H, W, Cin)), dtype)
+    wgt = q(rnd(name + "w", (Cout, Cin, k, k), std=(Cin * k * k) ** -0.5), dtype)
+    bias = rnd(name + "b", (Cout,), std=0.1)
+    ref = F.conv2d(x.permute(0, 3, 1, 2).double(), wgt.double(), bias.double(), padding=k // 2)
+    ref = {0: lambda v: v, 1: F.gelu, 2: lambda v: F.leaky_relu(v, 0.01)}[act](ref).permute(0, 2, 3, 1)
+    pw = ops.pack_conv_weight(wgt, bias, dt, dev)
+    ldx, ldo = _r8(Cin), _r8(Cout)
+    xd = to_dev(x, ldx, tdt, dev)
+    out = torch.zeros(B, H * W, ldo, dtype=tdt, device=dev)
+    ops.conv(pw, xd, out, B=B, H=H, W=W, dtype=dt, ldx=ldx, ldo=ldo, act=act, n_store=(Cout + 3) // 4 * 4)
+    torch.cuda.synchronize()
+    got = out[:, :, :Cout].float().reshape(B, H, W, Cout)
+    if dtype == "bf16":
+        ref = ref.float().to(torch.bfloat16).double()
+    check(got, ref, dtype, name)
+    assert float(out[:, :, (Cout + 3) // 4 * 4:].float().abs().max() if ldo > (Cout + 3) // 4 * 4 else 0.0) == 0.0
+
+
+@pytest.mark.parametrize("dtype", DT)
+def test_conv_residual_f32_and_r2_and_colsum(dtype):
+    """Epilogue: out_f32 = acc + bias + r1 + scale[n] * r2, split input source, per-tile column sums."""
+    dev, ops = _dev(), _ops()
+    dt = ops.DTYPE_CODE[dtype]
+    tdt = ops.TORCH_DTYPE[dt]
+    B, H, W, C = 2, 24, 40, 144
+    x = q(rnd("rx", (B, H, W, C)), dtype)
+    x0 = q(rnd("rx0", (B, H, W, 16)), dtype)
+    wgt = q(rnd("rw", (C, C, 1, 1), std=C ** -0.5), dtype)
+    bias = rnd("rb", (C,), std=0.1)
+    r1 = rnd("r1", (B, H, W, C))
+    r2 = q(rnd("r2", (B, H, W, C)), dtype)
+    sc = rnd("sc", (B, C), std=0.3)
+    xin = torch.cat([x0, x[..., 16:]], -1)
+    lin = F.conv2d(xin.permute(0, 3, 1, 2).double(), wgt.double(), bias.double()).permute(0, 2, 3, 1)
+    ref = lin + r1.double() + sc.double()[:, None, None, :] * r2.double()
+    pw = ops.pack_conv_weight(wgt, bias, dt, dev)
+    out = torch.zeros(B, H * W, C, dtype=torch.float32, device=dev)
+    tiles = ops.conv_tiles(pw, H, W, dt)
+    colsum = torch.zeros(B, tiles, pw.npad, dtype=torch.float32, device=dev)
+    scd = torch.zeros(B, pw.npad, device=dev)
+    scd[:, :C] = sc.to(dev)
+    ops.conv(pw, to_dev(x, C, tdt, dev), out, B=B, H=H, W=W, dtype=dt, ldx=C, ldo=C, out_mode=ops.O_NHWC_F32,
+             x0=to_dev(x0, 16, tdt, dev), c_split=16, ldx0=16, r1=r1.reshape(B, H * W, C).to(dev).contiguous(), ldr1=C,
+             r2=to_dev(r2, C, tdt, dev), ldr2=C, r2scale=scd, r2scale_bstride=pw.npad, colsum=colsum)
+    torch.cuda.synchronize()
+    check(out.reshape(B, H, W, C), ref, dtype, "residual epilogue", f32_tol=3e-5)
+    got_cs = colsum.sum(1)[:, :C]
+    check(got_cs / (H * W), ref.sum((1, 2)) / (H * W), dtype, "column sums", f32_tol=3e-5)
+
+
+@pytest.mark.parametrize("dtype", DT)
+def test_conv_f32_source_inplace_residual(dtype):
+    """RHAG tail (hat_arch.py:556): x read as fp32 tokens, out = conv3x3(x) + r1 written over r1."""
+    dev, ops = _dev(), _ops()
+    dt = ops.DTYPE_CODE[dtype]
+    B, H, W, C = 1, 32, 16, 144
+    x = rnd("fx", (B, H, W, C))
+    wgt = q(rnd("fw", (C, C, 3, 3), std=(9 * C) ** -0.5), dtype)
+    bias = rnd("fb", (C,), std=0.1)
+    r1 = rnd("fr", (B, H, W, C))
+    ref = F.conv2d(q(x, dtype).permute(0, 3, 1, 2).double(), wgt.double(), bias.double(), padding=1).permute(0, 2, 3, 1) + r1.double()
+    pw = ops.pack_conv_weight(wgt, bias, dt, dev)
+    xd = x.reshape(B, H * W, C).to(dev).contiguous()
+    rd = r1.reshape(B, H * W, C).to(dev).contiguous()
+    ops.conv(pw, xd, rd, B=B, H=H, W=W, dtype=dt, ldx=C, ldo=C, x_mode=ops.X_NHWC_F32, out_mode=ops.O_NHWC_F32, r1=rd, ldr1=C)
+    torch.cuda.synchronize()
+    check(rd.reshape(B, H, W, C), ref, dtype, "f32-source conv + in-place residual", f32_tol=3e-5)
+
+
+@pytest.mark.parametrize("dtype", DT)
+def test_conv_first_nchw_mean(dtype):
+    """(x - mean) * img_range then conv_first (hat_arch.py:849-853): NCHW fp32 in, fp32 tokens out."""
+    dev, ops = _dev(), _ops()
+    dt = ops.DTYPE_CODE[dtype]
+    B, H, W, C = 2, 24, 40, 144
+    x = synth.uniform(3, "cfx", (B, 3, H, W))
+    wgt = q(rnd("cfw", (C, 3, 3, 3), std=27 ** -0.5), dtype)
+    bias = rnd("cfb", (C,), std=0.1)
+    mean = torch.tensor(O.RGB_MEAN).view(1, 3, 1, 1)
+    xin = q((x - mean) * 1.0, dtype)
+    ref = F.conv2d(xin.double(), wgt.double(), bias.double(), padding=1).permute(0, 2, 3, 1)
+    pw = ops.pack_conv_weight(wgt, bias, dt, dev)
+    out = torch.zeros(B, H * W, C, dtype=torch.float32, device=dev)
+    ops.conv(pw, x.to(dev), out, B=B, H=H, W=W, dtype=dt, ldx=0, ldo=C, x_mode=ops.X_NCHW_F32_MEAN, out_mode=ops.O_NHWC_F32,
+             in_scale=1.0, mean=O.RGB_MEAN)
+    torch.cuda.synchronize()
+    check(out.reshape(B, H, W, C), ref, dtype, "conv_first")
+
+
+@pytest.mark.parametrize("dtype", DT)
+@pytest.mark.parametrize("r", [2, 3])
+def test_conv_pixelshuffle_and_last(dtype, r):
+    """Upsample conv + PixelShuffle folded into the store, then conv_last to NCHW (hat_arch.py:593-605,856-858)."""
+    dev, ops = _dev(), _ops()
+    dt = ops.DTYPE_CODE[dtype]
+    tdt = ops.TORCH_DTYPE[dt]
+    B, H, W = 1, 12, 20
+    x = q(rnd("px", (B, H, W, 64)), dtype)
+    w1 = q(rnd("pw", (64 * r * r, 64, 3, 3), std=576 ** -0.5), dtype)
+    b1 = rnd("pb", (64 * r * r,), std=0.1)
+    w2 = q(rnd("lw", (3, 64, 3, 3), std=576 ** -0.5), dtype)
+    b2 = rnd("lb", (3,), std=0.1)
+    up = F.pixel_shuffle(F.conv2d(x.permute(0, 3, 1, 2).double(), w1.double(), b1.double(), padding=1), r)
+    n = torch.arange(64 * r * r)
+    perm = (n % 64) * (r * r) + n // 64
+    pw1 = ops.pack_conv_weight(w1, b1, dt, dev, out_perm=perm)
+    mid = torch.zeros(B, H * r * W * r, 64, dtype=tdt, device=dev)
+    ops.conv(pw1, to_dev(x, 64, tdt, dev), mid, B=B, H=H, W=W, dtype=dt, ldx=64, ldo=64, out_mode=ops.O_PIXSHUF_T, ps_r=r)
+    torch.cuda.synchronize()
+    check(mid.float().reshape(B, H * r, W * r, 64), q(up.float(), dtype).double().permute(0, 2, 3, 1), dtype, "pixel shuffle")
+    up_q = mid.float().cpu().reshape(B, H * r, W * r, 64).permute(0, 3, 1, 2)
+    mean = torch.tensor(O.RGB_MEAN).view(1, 3, 1, 1)
+    ref = F.conv2d(up_q.double(), w2.double(), b2.double(), padding=1) / 2.0 + mean.double()
+    pw2 = ops.pack_conv_weight(w2, b2, dt, dev)
+    y = torch.zeros(B, 3, H * r, W * r, dtype=torch.float32, device=dev)
+    ops.conv(pw2, mid, y, B=B, H=H * r, W=W * r, dtype=dt, ldx=64, ldo=0, out_mode=ops.O_NCHW_F32, out_scale=0.5, mean=O.RGB_MEAN)
+    torch.cuda.synchronize()
+    check(y, ref, dtype, "conv_last")
+
+
+# ------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("dtype", DT)
+@pytest.mark.parametrize("C", [24, 144, 180])
+def test_layernorm(dtype, C):
+    dev, ops = _dev(), _ops()
+    dt = ops.DTYPE_CODE[dtype]
+    tdt = ops.TORCH_DTYPE[dt]
+    B, N = 2, 1000
+    x = rnd("lnx", (B, N, C), std=2.0) + 0.5
+    gm, bt = 1 + rnd("lng", (C,), std=0.1), rnd("lnb", (C,), std=0.1)
+    ref = F.layer_norm(x.double(), (C,), gm.double(), bt.double(), 1e-5)
+    ld = _r8(C)
+    y = torch.zeros(B, N, ld, dtype=tdt, device=dev)
+    gap = torch.zeros(B, ops.layernorm_blocks(), 16, device=dev)
+    gap_c = 16 if C >= 16 else 8
+    ops.layernorm(x.to(dev), y, gm.to(dev), bt.to(dev), B=B, npix=N, C_=C, ldy=ld, out_f32=False, dtype=dt, gap=gap, gap_c=gap_c)
+    yf = torch.zeros(B, N, C, device=dev)
+    ops.layernorm(x.to(dev), yf, gm.to(dev), bt.to(dev), B=B, npix=N, C_=C, ldy=C, out_f32=True, dtype=dt)
+    torch.cuda.synchronize()
+    check(y[:, :, :C].float(), ref, dtype, "layernorm -> T")
+    check(yf, ref, "f32", "layernorm -> fp32")
+    check(gap.sum(1)[:, :gap_c] / N, ref[:, :, :gap_c].mean(1), "f32", "gap partial sums", f32_tol=1e-5)
+
+
+@pytest.mark.parametrize("dtype", DT)
+def test_dwconv_gate(dtype):
+    dev, ops = _dev(), _ops()
+    dt = ops.DTYPE_CODE[dtype]
+    tdt = ops.TORCH_DTYPE[dt]
+    B, H, W, hid = 2, 19, 23, 288
+    u = q(rnd("dwu", (B, H, W, 2 * hid)), dtype)
+    wd, bd = rnd("dww", (2 * hid, 1, 3, 3), std=1 / 3), rnd("dwb", (2 * hid,), std=0.1)
+    v = F.conv2d(u.permute(0, 3, 1, 2).double(), wd.double(), bd.double(), padding=1, groups=2 * hid).permute(0, 2, 3, 1)
+    a, g = v.chunk(2, dim=-1)
+    ref = a * F.silu(g)
+    out = torch.zeros(B, H * W, hid, dtype=tdt, device=dev)
+    ops.dwconv_gate(to_dev(u, 2 * hid, tdt, dev), wd.reshape(2 * hid, 9).t().contiguous().to(dev), bd.to(dev), out, B=B, H=H,
+                    W=W, hid=hid, ldu=2 * hid, ldo=hid, dtype=dt)
+    torch.cuda.synchronize()
+    check(out.float().reshape(B, H, W, hid), ref, dtype, "dwconv+gate")
+
+
+@pytest.mark.parametrize("dtype", DT)
+@pytest.mark.parametrize("geom", [(16, 6, 144, 32, 48), (16, 6, 180, 32, 16), (8, 2, 24, 16, 24)],
+                         ids=["ws16_d24", "ws16_d30", "ws8_d12"])
+def test_ocab_attention(dtype, geom):
+    ws, heads, C, H, W = geom
+    dev, ops = _dev(), _ops()
+    dt = ops.DTYPE_CODE[dtype]
+    tdt = ops.TORCH_DTYPE[dt]
+    B = 2
+    wse = ws + ws // 2
+    d = C // heads
+    qv = q(rnd("aq", (B, H, W, C)) * d ** -0.5, dtype)
+    kv = q(rnd("akv", (B, H, W, 2 * C)), dtype)
+    table = rnd("atab", ((ws + wse - 1) ** 2, heads), std=0.5)
+    rpi = O.rpi_oca(ws, 0.5)
+    ref = O.ocab_attention(qv.double(), kv[..., :C].double(), kv[..., C:].double(), table.double(), rpi, ws, wse, heads, 1.0)
+    M = ws + wse - 1
+    shift = (ws - wse + 1 - (ws - 1)) * (M + 1)
+    rot = (torch.arange(M * M) + shift) % (M * M)
+    bias_rot = table[rot].t().contiguous().to(dev)
+    out = torch.zeros(B, H * W, _r8(C), dtype=tdt, device=dev)
+    ops.ocab_attention(to_dev(qv, _r8(C), tdt, dev), to_dev(kv, _r8(2 * C), tdt, dev), bias_rot, out, B=B, H=H, W=W, C_=C,
+                       heads=heads, ws=ws, wse=wse, ldq=_r8(C), ldkv=_r8(2 * C), ldo=_r8(C), dtype=dt)
+    torch.cuda.synchronize()
+    check(out[:, :, :C].float().reshape(B, H, W, C), ref, dtype, "ocab attention", f32_tol=5e-5)
+
+
+def test_ocab_attention_softmax_spike():
+    """A large logit in a late key chunk forces the online-softmax rescale branch (guide rule 26)."""
+    dev, ops = _dev(), _ops()
+    ws, heads, C, H, W, B = 16, 6, 144, 16, 16, 1
+    wse, d = 24, 24
+    qv = rnd("sq", (B, H, W, C)) * d ** -0.5
+    kv = rnd("skv", (B, H, W, 2 * C))
+    kv[0, 15, 15, :C] *= 40.0  # bottom-right key: last key chunk of the window
+    table = rnd("stab", ((ws + wse - 1) ** 2, heads), std=0.5)
+    ref = O.ocab_attention(qv.double(), kv[..., :C].double(), kv[..., C:].double(), table.double(), O.rpi_oca(ws, 0.5), ws, wse, heads, 1.0)
+    M = ws + wse - 1
+    rot = (torch.arange(M * M) + (ws - wse + 1 - (ws - 1)) * (M + 1)) % (M * M)
+    out = torch.zeros(B, H * W, C, device=dev)
+    ops.ocab_attention(qv.reshape(B, H * W, C).to(dev), kv.reshape(B, H * W, 2 * C).to(dev), table[rot].t().contiguous().to(dev),
+                       out, B=B, H=H, W=W, C_=C, heads=heads, ws=ws, wse=wse, ldq=C, ldkv=2 * C, ldo=C, dtype=ops.HAT_F32)
+    torch.cuda.synchronize()
+    check(out.reshape(B, H, W, C), ref, "f32", "attention with a logit spike", f32_tol=1e-4)
+
+
+@pytest.mark.parametrize("dtype", DT)
+@pytest.mark.parametrize("pdim,ks", [(16, 13), (8, 5)])
+def test_esc_weights_and_eca(dtype, pdim, ks):
+    dev, ops = _dev(), _ops()
+    dt = ops.DTYPE_CODE[dtype]
+    tdt = ops.TORCH_DTYPE[dt]
+    B, N, nblk = 2, 777, ops.layernorm_blocks()
+    gap = rnd("gp", (B, nblk, 16), std=1.0)
+    gap[:, :, pdim:] = 0
+    w1, b1 = rnd("w1", (pdim // 2, pdim), std=0.3), rnd("b1", (pdim // 2,), std=0.1)
+    w2, b2 = rnd("w2", (pdim * 9, pdim // 2), std=0.3), rnd("b2", (pdim * 9,), std=0.1)
+    plk = rnd("plk", (pdim, pdim, ks, ks), std=0.05)
+    p = gap.double().sum(1)[:, :pdim] / N
+    h = F.gelu(p @ w1.double().t() + b1.double())
+    dk = (h @ w2.double().t() + b2.double()).reshape(B, pdim, 3, 3)
+    weff = plk.double()[None].repeat(B, 1, 1, 1, 1)
+    c = ks // 2
+    for i in range(pdim):
+        weff[:, i, i, c - 1:c + 2, c - 1:c + 2] += dk[:, i]
+    lk = ops.pack_conv_weight(plk, None, ops.HAT_F32, dev, nt=1)
+    kc = ops.KC[dt]
+    kpad = -(-(ks * ks * _r8(pdim)) // kc) * kc
+    plkp = torch.zeros(16, kpad, device=dev)
+    plkp[:, :min(kpad, lk.kpad)] = lk.w[:16, :min(kpad, lk.kpad)]
+    wout = torch.full((B, 16, kpad), 7.0, dtype=tdt, device=dev)
+    ops.esc_weights(gap.to(dev), nblk, N, w1.to(dev), b1.to(dev), w2.to(dev), b2.to(dev), plkp, wout, B=B, pdim=pdim, ksize=ks,
+                    kpad=kpad, dtype=dt)
+    torch.cuda.synchronize()
+    cin_p = _r8(pdim)
+    got = wout.float().cpu()[:, :pdim, :ks * ks * cin_p].reshape(B, pdim, ks, ks, cin_p)[..., :pdim].permute(0, 1, 4, 2, 3)
+    check(got, weff, dtype, "esc weights", f32_tol=1e-5)
+    assert float(wout[:, pdim:].float().abs().max()) == 0.0 if pdim < 16 else True
+    # ECA
+    C, tiles, ldc = 144, 37, 144
+    cs = rnd("cs", (B, tiles, ldc), std=3.0)
+    wk = rnd("wk", (5,), std=0.5)
+    m = cs.double().sum(1) / N
+    e = F.conv1d(m[:, None, :], wk.double()[None, None], padding=2)[:, 0]
+    ref = 0.01 * torch.sigmoid(e)
+    scale = torch.zeros(B, ldc, device=dev)
+    ops.eca_scale(cs.to(dev), tiles, ldc, N, wk.to(dev), 5, 0.01, torch.zeros(B, 32, ldc, device=dev), scale, B=B, C_=C)
+    torch.cuda.synchronize()
+    check(scale[:, :C], ref, "f32", "eca scale", f32_tol=1e-6)
