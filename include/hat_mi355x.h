@@ -81,6 +81,9 @@ typedef struct HatConvDesc {
 
 /* Number of spatial tiles hat_conv uses for (H, W, Cin, ksize, nt, dtype): the leading dimension of `colsum`. */
 int hat_conv_tiles(const HatConvDesc* d, int32_t* tiles_out);
+/* The launch plan hat_conv picks for `d`: waves per workgroup, pixel rows per wave, spatial tiles and dynamic
+ * LDS bytes.  The kernel instantiation is conv_kernel<T, waves, rows_per_wave, nt> (used to label profiles). */
+int hat_conv_plan(const HatConvDesc* d, int32_t* waves, int32_t* rows_per_wave, int32_t* tiles, int64_t* lds_bytes);
 int hat_conv(const HatConvDesc* d, void* stream);
 
 /*

@@ -47,6 +47,8 @@ SIGNATURES = {
     "hat_abi_version": (C.c_int, []),
     "hat_target_arch": (C.c_char_p, []),
     "hat_conv_tiles": (C.c_int, [C.POINTER(HatConvDesc), C.POINTER(C.c_int32)]),
+    "hat_conv_plan": (C.c_int, [C.POINTER(HatConvDesc), C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.POINTER(C.c_int32),
+                                C.POINTER(C.c_int64)]),
     "hat_conv": (C.c_int, [C.POINTER(HatConvDesc), C.c_void_p]),
     "hat_layernorm_blocks": (C.c_int, []),
     "hat_layernorm": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int64,

@@ -318,6 +318,15 @@ extern "C" int hat_conv_tiles(const HatConvDesc* d, int32_t* tiles_out) {
     return 0;
 }
 
+extern "C" int hat_conv_plan(const HatConvDesc* d, int32_t* waves, int32_t* rows_per_wave, int32_t* tiles, int64_t* lds_bytes) {
+    if (!d || !waves || !rows_per_wave || !tiles || !lds_bytes) return HAT_EINVAL;
+    TileCfg tc; size_t lds;
+    if (!conv_pick(*d, &tc, &lds)) return HAT_ELDS;
+    *waves = tc.waves; *rows_per_wave = tc.pt; *lds_bytes = (int64_t)lds;
+    *tiles = ((d->W + 15) / 16) * ((d->H + tc.waves * tc.pt - 1) / (tc.waves * tc.pt));
+    return 0;
+}
+
 extern "C" int hat_conv(const HatConvDesc* dp, void* stream) {
     if (!dp) return HAT_EINVAL;
     const HatConvDesc& d = *dp;

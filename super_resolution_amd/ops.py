@@ -32,6 +32,39 @@ def _stream() -> int:
     return torch.cuda.current_stream().cuda_stream
 
 
+# ---- optional per-launch timing (bench.py): HIP events on the stream the kernels are enqueued on ----
+_prof = None  # None, or a list of (kernel_name, algorithmic_flops, start_event, end_event)
+
+
+class profile:
+    """`with ops.profile() as records:` brackets every kernel launch with HIP events on the current
+    stream and records (kernel name as rocprof prints it, algorithmic FLOPs of the launch)."""
+
+    def __enter__(self):
+        global _prof
+        _prof = []
+        return _prof
+
+    def __exit__(self, *exc):
+        global _prof
+        _prof = None
+        return False
+
+
+def _timed(name, flops, fn):
+    if _prof is None:
+        return fn()
+    s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    s.record()
+    r = fn()
+    e.record()
+    _prof.append((name, float(flops), s, e))
+    return r
+
+
+_TNAME = {HAT_F32: "float", HAT_BF16: "__bf16"}
+
+
 class PackedConv:
     """Packed weights of one conv/linear layer (see HatConvDesc in include/hat_mi355x.h)."""
     __slots__ = ("w", "bias", "ksize", "cin", "kpad", "nt", "n_slices", "nout", "w_bstride")
@@ -108,7 +141,16 @@ def conv(pw: PackedConv, x: torch.Tensor, out: torch.Tensor, *, B: int, H: int, 
     for i in range(4):
         d.mean[i] = float(mean[i]) if i < len(mean) else 0.0
     d.dtype = dtype
-    _lib.check(lib.hat_conv(C.byref(d), _stream()), f"hat_conv(k={pw.ksize}, Cin={d.Cin}, N={pw.nout})")
+    name, flops = "conv_kernel", 0.0
+    if _prof is not None:
+        wv, pt, tl, lds = C.c_int32(0), C.c_int32(0), C.c_int32(0), C.c_int64(0)
+        lib.hat_conv_plan(C.byref(d), C.byref(wv), C.byref(pt), C.byref(tl), C.byref(lds))
+        name = f"conv_kernel<{_TNAME[dtype]}, {wv.value}, {pt.value}, {pw.nt}>"
+        # algorithmic FLOPs (2*MAC, unpadded).  The 13x13 ESC conv also carries the
+        # dynamic depthwise 3x3 that is folded into its weights (2*9*pdim per pixel).
+        flops = 2.0 * B * H * W * (pw.ksize ** 2) * d.Cin * pw.nout + (2.0 * 9 * pw.nout * B * H * W if pw.w_bstride else 0.0)
+    _timed(name, flops, lambda: _lib.check(lib.hat_conv(C.byref(d), _stream()),
+                                           f"hat_conv(k={pw.ksize}, Cin={d.Cin}, N={pw.nout})"))
 
 
 def conv_tiles(pw: PackedConv, H: int, W: int, dtype: int) -> int:
@@ -127,31 +169,36 @@ def layernorm_blocks() -> int:
 def layernorm(x: torch.Tensor, y: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, *, B: int, npix: int, C_: int,
               ldy: int, out_f32: bool, dtype: int, gap: Optional[torch.Tensor] = None, gap_c: int = 0):
     lib = _lib.load()
-    _lib.check(lib.hat_layernorm(_ptr(x), _ptr(y), _ptr(gamma), _ptr(beta), _ptr(gap), B, npix, C_, ldy, int(out_f32),
-                                 gap_c, dtype, _stream()), "hat_layernorm")
+    _timed("ln_kernel", 0.0, lambda: _lib.check(
+        lib.hat_layernorm(_ptr(x), _ptr(y), _ptr(gamma), _ptr(beta), _ptr(gap), B, npix, C_, ldy, int(out_f32), gap_c, dtype,
+                          _stream()), "hat_layernorm"))
 
 
 def esc_weights(gap: torch.Tensor, nblk: int, npix: int, w1, b1, w2, b2, plk_packed, w_out, *, B: int, pdim: int,
                 ksize: int, kpad: int, dtype: int):
     lib = _lib.load()
-    _lib.check(lib.hat_esc_weights(_ptr(gap), nblk, npix, _ptr(w1), _ptr(b1), _ptr(w2), _ptr(b2), _ptr(plk_packed),
-                                   _ptr(w_out), B, pdim, ksize, kpad, dtype, _stream()), "hat_esc_weights")
+    _timed("esc_weights_kernel", 0.0, lambda: _lib.check(
+        lib.hat_esc_weights(_ptr(gap), nblk, npix, _ptr(w1), _ptr(b1), _ptr(w2), _ptr(b2), _ptr(plk_packed), _ptr(w_out), B,
+                            pdim, ksize, kpad, dtype, _stream()), "hat_esc_weights"))
 
 
 def eca_scale(colsum, tiles: int, ldc: int, npix: int, wk, k: int, conv_scale: float, tmp, scale, *, B: int, C_: int):
     lib = _lib.load()
-    _lib.check(lib.hat_eca_scale(_ptr(colsum), tiles, ldc, npix, _ptr(wk), k, conv_scale, _ptr(tmp), _ptr(scale), B, C_,
-                                 _stream()), "hat_eca_scale")
+    _timed("eca_reduce+scale", 0.0, lambda: _lib.check(
+        lib.hat_eca_scale(_ptr(colsum), tiles, ldc, npix, _ptr(wk), k, conv_scale, _ptr(tmp), _ptr(scale), B, C_, _stream()),
+        "hat_eca_scale"))
 
 
 def dwconv_gate(u, wdw, bdw, out, *, B: int, H: int, W: int, hid: int, ldu: int, ldo: int, dtype: int):
     lib = _lib.load()
-    _lib.check(lib.hat_dwconv_gate(_ptr(u), _ptr(wdw), _ptr(bdw), _ptr(out), B, H, W, hid, ldu, ldo, dtype, _stream()),
-               "hat_dwconv_gate")
+    _timed(f"dwgate_kernel<{_TNAME[dtype]}>", 2.0 * 9 * 2 * hid * B * H * W, lambda: _lib.check(
+        lib.hat_dwconv_gate(_ptr(u), _ptr(wdw), _ptr(bdw), _ptr(out), B, H, W, hid, ldu, ldo, dtype, _stream()),
+        "hat_dwconv_gate"))
 
 
 def ocab_attention(q, kv, bias_rot, out, *, B: int, H: int, W: int, C_: int, heads: int, ws: int, wse: int, ldq: int,
                    ldkv: int, ldo: int, dtype: int):
     lib = _lib.load()
-    _lib.check(lib.hat_ocab_attention(_ptr(q), _ptr(kv), _ptr(bias_rot), _ptr(out), B, H, W, C_, heads, ws, wse, ldq,
-                                      ldkv, ldo, dtype, _stream()), "hat_ocab_attention")
+    _timed(f"ocab_attn_kernel<{_TNAME[dtype]}>", 2.0 * 2 * wse * wse * C_ * B * H * W, lambda: _lib.check(
+        lib.hat_ocab_attention(_ptr(q), _ptr(kv), _ptr(bias_rot), _ptr(out), B, H, W, C_, heads, ws, wse, ldq, ldkv, ldo, dtype,
+                               _stream()), "hat_ocab_attention"))
