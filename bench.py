@@ -211,7 +211,9 @@ def main():
             "kernels": kernels,
         }
         if world == 1 and args.cpu_crop > 0:
-            res["cpu_baseline"] = cpu_baseline(args.model, s, args.cpu_crop, os.cpu_count() or 1)
+            # the GPU box gives one GPU a share of 16 host cores; more threads than that only oversubscribe
+            cores = min(16, len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1))
+            res["cpu_baseline"] = cpu_baseline(args.model, s, args.cpu_crop, cores)
             res["cpu_baseline"]["gpu_over_cpu"] = round(value / res["cpu_baseline"]["value"], 1)
         else:
             res["cpu_baseline"] = None

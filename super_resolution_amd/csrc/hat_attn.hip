@@ -178,7 +178,7 @@ int launch_attn(const void* q, const void* kv, const float* bias_rot, void* out,
         if (e != hipSuccess) return (int)e;
     }
     dim3 grid(W / ws, H / ws, B * heads);
-    hipLaunchKernelGGL(kern, grid, dim3(256), lds, s, reinterpret_cast<const T*>(q), reinterpret_cast<const T*>(kv), bias_rot,
+    HAT_LAUNCH(kern, grid, dim3(256), lds, s, reinterpret_cast<const T*>(q), reinterpret_cast<const T*>(kv), bias_rot,
                        reinterpret_cast<T*>(out), H, W, C, heads, ws, wse, ldq, ldkv, ldo);
     return hat_check_launch();
 }

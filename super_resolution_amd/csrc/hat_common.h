@@ -103,6 +103,14 @@ __host__ __device__ inline int lds_row_elems(int n, int es) {
 
 __device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
 
+// Launch status.  Every launch site first drains hipGetLastError(): the value is per-thread state that
+// other libraries in the process (e.g. a failed probe inside the framework) may have left set.
+#define HAT_LAUNCH(...)                      \
+    do {                                     \
+        (void)hipGetLastError();             \
+        hipLaunchKernelGGL(__VA_ARGS__);     \
+    } while (0)
+
 static inline int hat_check_launch() {
     hipError_t e = hipGetLastError();
     return e == hipSuccess ? 0 : (int)e;

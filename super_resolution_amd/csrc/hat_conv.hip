@@ -252,7 +252,7 @@ int launch_conv(const HatConvDesc& d, size_t lds, hipStream_t stream) {
         if (e != hipSuccess) return (int)e;
     }
     dim3 grid((d.W + 15) / 16, (d.H + WAVES * PT - 1) / (WAVES * PT), d.B);
-    hipLaunchKernelGGL(kern, grid, dim3(WAVES * 64), lds, stream, d);
+    HAT_LAUNCH(kern, grid, dim3(WAVES * 64), lds, stream, d);
     return hat_check_launch();
 }
 

@@ -91,10 +91,10 @@ int launch_ln(const float* x, void* y, const float* gamma, const float* beta, fl
     const int nv = (C + 63) / 64;
     OutT* yo = reinterpret_cast<OutT*>(y);
     switch (nv) {
-        case 1: hipLaunchKernelGGL((ln_kernel<OutT, 1>), grid, block, 0, s, x, yo, gamma, beta, gap, npix, C, ldy, gap_c); break;
-        case 2: hipLaunchKernelGGL((ln_kernel<OutT, 2>), grid, block, 0, s, x, yo, gamma, beta, gap, npix, C, ldy, gap_c); break;
-        case 3: hipLaunchKernelGGL((ln_kernel<OutT, 3>), grid, block, 0, s, x, yo, gamma, beta, gap, npix, C, ldy, gap_c); break;
-        case 4: hipLaunchKernelGGL((ln_kernel<OutT, 4>), grid, block, 0, s, x, yo, gamma, beta, gap, npix, C, ldy, gap_c); break;
+        case 1: HAT_LAUNCH((ln_kernel<OutT, 1>), grid, block, 0, s, x, yo, gamma, beta, gap, npix, C, ldy, gap_c); break;
+        case 2: HAT_LAUNCH((ln_kernel<OutT, 2>), grid, block, 0, s, x, yo, gamma, beta, gap, npix, C, ldy, gap_c); break;
+        case 3: HAT_LAUNCH((ln_kernel<OutT, 3>), grid, block, 0, s, x, yo, gamma, beta, gap, npix, C, ldy, gap_c); break;
+        case 4: HAT_LAUNCH((ln_kernel<OutT, 4>), grid, block, 0, s, x, yo, gamma, beta, gap, npix, C, ldy, gap_c); break;
         default: return HAT_EUNSUPPORTED;
     }
     return hat_check_launch();
@@ -266,10 +266,10 @@ extern "C" int hat_esc_weights(const float* gap_partial, int32_t nblk, int64_t n
     dim3 grid(16, B), block(256);
     const float inv = 1.0f / (float)npix;
     if (dtype == HAT_BF16)
-        hipLaunchKernelGGL(esc_weights_kernel<bf16_t>, grid, block, 0, s, gap_partial, nblk, inv, w1, b1, w2, b2, plk_packed,
+        HAT_LAUNCH(esc_weights_kernel<bf16_t>, grid, block, 0, s, gap_partial, nblk, inv, w1, b1, w2, b2, plk_packed,
                            reinterpret_cast<bf16_t*>(w_out), pdim, ksize, Kpad);
     else if (dtype == HAT_F32)
-        hipLaunchKernelGGL(esc_weights_kernel<float>, grid, block, 0, s, gap_partial, nblk, inv, w1, b1, w2, b2, plk_packed,
+        HAT_LAUNCH(esc_weights_kernel<float>, grid, block, 0, s, gap_partial, nblk, inv, w1, b1, w2, b2, plk_packed,
                            reinterpret_cast<float*>(w_out), pdim, ksize, Kpad);
     else
         return HAT_EINVAL;
@@ -280,10 +280,10 @@ extern "C" int hat_eca_scale(const float* colsum, int32_t tiles, int32_t ldc, in
                              float conv_scale, float* tmp, float* scale, int32_t B, int32_t C, void* stream) {
     if (!colsum || !wk || !tmp || !scale || tiles < 1 || ldc < C || ldc > 256 || C < 1 || k < 1 || (k & 1) == 0 || B < 1) return HAT_EINVAL;
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
-    hipLaunchKernelGGL(eca_reduce_kernel, dim3(32, B), dim3(256), 0, s, colsum, tiles, ldc, tmp);
+    HAT_LAUNCH(eca_reduce_kernel, dim3(32, B), dim3(256), 0, s, colsum, tiles, ldc, tmp);
     int rc = hat_check_launch();
     if (rc) return rc;
-    hipLaunchKernelGGL(eca_scale_kernel, dim3(B), dim3(256), 0, s, tmp, ldc, 1.0f / (float)npix, wk, k, conv_scale, scale, C);
+    HAT_LAUNCH(eca_scale_kernel, dim3(B), dim3(256), 0, s, tmp, ldc, 1.0f / (float)npix, wk, k, conv_scale, scale, C);
     return hat_check_launch();
 }
 
@@ -294,10 +294,10 @@ extern "C" int hat_dwconv_gate(const void* u, const float* wdw, const float* bdw
     const size_t total = (size_t)B * H * W * (hid / 4);
     const int blocks = (int)((total + 255) / 256 < 8192 ? (total + 255) / 256 : 8192);
     if (dtype == HAT_BF16)
-        hipLaunchKernelGGL(dwgate_kernel<bf16_t>, dim3(blocks), dim3(256), 0, s, reinterpret_cast<const bf16_t*>(u), wdw, bdw,
+        HAT_LAUNCH(dwgate_kernel<bf16_t>, dim3(blocks), dim3(256), 0, s, reinterpret_cast<const bf16_t*>(u), wdw, bdw,
                            reinterpret_cast<bf16_t*>(out), B, H, W, hid, ldu, ldo);
     else if (dtype == HAT_F32)
-        hipLaunchKernelGGL(dwgate_kernel<float>, dim3(blocks), dim3(256), 0, s, reinterpret_cast<const float*>(u), wdw, bdw,
+        HAT_LAUNCH(dwgate_kernel<float>, dim3(blocks), dim3(256), 0, s, reinterpret_cast<const float*>(u), wdw, bdw,
                            reinterpret_cast<float*>(out), B, H, W, hid, ldu, ldo);
     else
         return HAT_EINVAL;

@@ -123,8 +123,9 @@ def tile_parallel_forward(img: torch.Tensor, net: Callable, scale: int, tiles: S
     for s, i in enumerate(owned[rank]):
         o = run_tile(img, net, tiles[i], scale)
         send[s, :, :, :o.shape[2], :o.shape[3]] = o
-    recv = torch.empty((world,) + tuple(send.shape), dtype=img.dtype, device=img.device)
-    dist.all_gather_into_tensor(recv, send, group=group)
+    recv = torch.empty((world * slots,) + tuple(send.shape[1:]), dtype=img.dtype, device=img.device)
+    dist.all_gather_into_tensor(recv, send, group=group)  # concatenation along dim 0, rank-major
+    recv = recv.view((world, slots) + tuple(send.shape[1:]))
     if out is None:
         out = img.new_zeros((b, c, h * scale, w * scale))
     for r in range(world):

@@ -99,7 +99,8 @@ def test_product_path_has_no_cpu_fallback():
     for dp, _, fs in os.walk(pkg):
         for f in fs:
             if f.endswith(".py"):
-                assert "oracle" not in open(os.path.join(dp, f)).read().replace("no oracle", ""), f
+                src = open(os.path.join(dp, f)).read()
+                assert not re.search(r"^\s*(from|import)\s+oracle\b", src, flags=re.M), f"{f} imports the oracle"
 
 
 def test_registry_semantics():
