@@ -80,6 +80,11 @@ def load():
             raise RuntimeError(
                 f"{LIB_PATH} not found: the HIP kernels are not built. Run `python -m super_resolution_amd.build` "
                 "(needs hipcc). There is no CPU fallback for the HAT forward pass.")
+        # Load PyTorch's HIP runtime FIRST.  torch links "libamdhip64.so" (its bundled copy, found through
+        # its own RPATH) while this library links "libamdhip64.so.7": if ours were loaded first the process
+        # would end up with two HIP runtimes and our launches would target the one torch never initialised
+        # (hipErrorNoDevice).  With torch's copy resident, our NEEDED entry resolves to it by SONAME.
+        import torch  # noqa: F401
         lib = C.CDLL(LIB_PATH)
         for name, (res, args) in SIGNATURES.items():
             fn = getattr(lib, name, None)
