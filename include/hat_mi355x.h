@@ -135,6 +135,44 @@ int hat_ocab_attention(const void* q, const void* kv, const float* bias_rot, voi
                        int32_t W, int32_t C, int32_t heads, int32_t ws, int32_t wse, int32_t ldq,
                        int32_t ldkv, int32_t ldo, int32_t dtype, void* stream);
 
+/*
+ * Fused HAB feed-forward half (hat_arch.py:237 with :107-119):
+ *     t_out = t_in + fc2( a * SiLU(g) ),  [a | g] = dwconv3x3( fc1( LayerNorm2(t_in) ) )
+ * in ONE kernel: the 4C-wide intermediate never leaves the CU (LDS), HBM traffic is one read and one
+ * write of the fp32 residual stream.  Optionally also emits the NEXT block's LayerNorm of t_out
+ * (n_out, T) and its ESC global-average-pool partials (gap_out[b][tile][16]), saving that pass.
+ * t_out must not alias t_in (3x3 halo).  Weights are "fragment packed" by the host:
+ *   w1f [chunk][4][KS][64 lanes][8]  : fc1 rows {a: 32c..32c+31, g: hid_p+32c..} of chunk c, MFMA A-fragment order
+ *   w2f [chunk][nt][64 lanes][8]     : fc2 columns 32c..32c+31
+ *   dww : depthwise weights, bf16: [chunk][4 octets][9 taps][a|g][8 dwords = (w,0),(0,w) bf16 pairs]
+ *                            f32 : [chunk][8 quads][9 taps][a|g][4 floats]
+ *   b1, dwb : [2*hid_p] fp32 (a-part then g-part), b2 : [nt*16] fp32; hid_p = 32*chunks >= hidden, zero padded.
+ * Spatial tile = (2*waves) rows x 16 columns; hat_ffn_tiles() returns the tile count (leading dim of gap_out).
+ */
+typedef struct HatFfnDesc {
+    const float* t_in;
+    float* t_out;
+    const float* ln_g;
+    const float* ln_b;
+    const void* w1f;
+    const float* b1;
+    const void* dww;
+    const float* dwb;
+    const void* w2f;
+    const float* b2;
+    const float* ln1_g;  /* optional fused next LayerNorm (NULL: off) */
+    const float* ln1_b;
+    void* n_out;         /* (B,H,W,ldn) T */
+    float* gap_out;      /* optional [B][tiles][16] */
+    int32_t B, H, W, C;
+    int32_t chunks;      /* hid_p / 32 */
+    int32_t ldn, gap_c;
+    int32_t dtype;
+} HatFfnDesc;
+
+int hat_ffn_tiles(const HatFfnDesc* d, int32_t* tiles_out);
+int hat_ffn(const HatFfnDesc* d, void* stream);
+
 int hat_abi_version(void);
 /* name of the architecture the code objects in this library were compiled for ("gfx950") */
 const char* hat_target_arch(void);

@@ -42,6 +42,18 @@ class HatConvDesc(C.Structure):
     ]
 
 
+class HatFfnDesc(C.Structure):
+    """Mirror of `struct HatFfnDesc` (include/hat_mi355x.h)."""
+    _fields_ = [
+        ("t_in", C.c_void_p), ("t_out", C.c_void_p), ("ln_g", C.c_void_p), ("ln_b", C.c_void_p),
+        ("w1f", C.c_void_p), ("b1", C.c_void_p), ("dww", C.c_void_p), ("dwb", C.c_void_p),
+        ("w2f", C.c_void_p), ("b2", C.c_void_p), ("ln1_g", C.c_void_p), ("ln1_b", C.c_void_p),
+        ("n_out", C.c_void_p), ("gap_out", C.c_void_p),
+        ("B", C.c_int32), ("H", C.c_int32), ("W", C.c_int32), ("C", C.c_int32),
+        ("chunks", C.c_int32), ("ldn", C.c_int32), ("gap_c", C.c_int32), ("dtype", C.c_int32),
+    ]
+
+
 # name -> (restype, argtypes); every symbol declared in include/hat_mi355x.h
 SIGNATURES = {
     "hat_abi_version": (C.c_int, []),
@@ -50,6 +62,8 @@ SIGNATURES = {
     "hat_conv_plan": (C.c_int, [C.POINTER(HatConvDesc), C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.POINTER(C.c_int32),
                                 C.POINTER(C.c_int64)]),
     "hat_conv": (C.c_int, [C.POINTER(HatConvDesc), C.c_void_p]),
+    "hat_ffn_tiles": (C.c_int, [C.POINTER(HatFfnDesc), C.POINTER(C.c_int32)]),
+    "hat_ffn": (C.c_int, [C.POINTER(HatFfnDesc), C.c_void_p]),
     "hat_layernorm_blocks": (C.c_int, []),
     "hat_layernorm": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int64,
                                 C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_void_p]),

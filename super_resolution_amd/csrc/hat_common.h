@@ -37,6 +37,12 @@ template <> struct MT<bf16_t> {
     static __device__ __forceinline__ f32x4 mma(frag_t a, frag_t b, f32x4 c) {
         return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
     }
+    // half k-step (16 deep): v_mfma_f32_16x16x16_bf16, lane l holds A[row l&15][k = 4*(l>>4)+j], j = 0..3
+    typedef short half_t __attribute__((ext_vector_type(4)));
+    static __device__ __forceinline__ half_t load_half(const bf16_t* p) { return *reinterpret_cast<const half_t*>(p); }
+    static __device__ __forceinline__ f32x4 mma_half(half_t a, half_t b, f32x4 c) {
+        return __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(a, b, c, 0, 0, 0);
+    }
 };
 
 template <> struct MT<float> {
@@ -60,6 +66,14 @@ template <> struct MT<float> {
     static __device__ __forceinline__ f32x4 mma(frag_t a, frag_t b, f32x4 c) {
 #pragma unroll
         for (int j = 0; j < 8; ++j) c = __builtin_amdgcn_mfma_f32_16x16x4f32(a[j], b[j], c, 0, 0, 0);
+        return c;
+    }
+    // half k-step (16 deep): four 16x16x4 MFMAs, element j <-> k = 4*(l>>4)+j
+    typedef f32x4 half_t;
+    static __device__ __forceinline__ half_t load_half(const float* p) { return *reinterpret_cast<const f32x4*>(p); }
+    static __device__ __forceinline__ f32x4 mma_half(half_t a, half_t b, f32x4 c) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) c = __builtin_amdgcn_mfma_f32_16x16x4f32(a[j], b[j], c, 0, 0, 0);
         return c;
     }
 };

@@ -77,6 +77,10 @@ class HATEngine:
         self.scale = cfg["upscale"]
         self._ws_cache = {}
         ops._lib.load()
+        # fused FFN kernel (hat_ffn) for the shapes it is instantiated for; HAT_NO_FUSED_FFN=1 forces the
+        # unfused kernel sequence (fc1 -> dw+gate -> fc2), kept for A/B validation of the fusion
+        import os
+        self.fuse_ffn = ops.ffn_supported(self.C) and os.environ.get("HAT_NO_FUSED_FFN", "0") != "1"
         self._pack(state_dict)
 
     # ------------------------------------------------------------------------------------------
@@ -109,6 +113,9 @@ class HATEngine:
                 hid2 = sd[p + ".mlp.dw.weight"].shape[0]
                 hb["dw_w"] = sd[p + ".mlp.dw.weight"].detach().to(**f32).reshape(hid2, 9).t().contiguous()  # [9][2*hid]
                 hb["dw_b"] = vec(p + ".mlp.dw.bias")
+                if self.fuse_ffn:
+                    hb["ffn"] = ops.pack_ffn(sd[p + ".mlp.fc1.weight"], sd[p + ".mlp.fc1.bias"], sd[p + ".mlp.dw.weight"],
+                                             sd[p + ".mlp.dw.bias"], sd[p + ".mlp.fc2.weight"], sd[p + ".mlp.fc2.bias"], dt, dev)
                 L["habs"].append(hb)
             p = f"layers.{g}.residual_group.overlap_attn"
             d = C // heads
@@ -168,12 +175,12 @@ class HATEngine:
         z = lambda *shape, dtype=T: torch.zeros(*shape, dtype=dtype, device=dev)
         f = torch.float32
         w = {
-            "f0": z(B, N, C, dtype=f), "tA": z(B, N, C, dtype=f), "tB": z(B, N, C, dtype=f),
+            "f0": z(B, N, C, dtype=f), "tA": z(B, N, C, dtype=f), "tB": z(B, N, C, dtype=f), "tC": z(B, N, C, dtype=f),
             "n": z(B, N, _r8(C)), "c1": z(B, N, _r8(mid)), "c2": z(B, N, _r8(C)),
             "y16": z(B, N, 16), "u": z(B, N, _r8(max(hid2, 2 * C))), "g": z(B, N, _r8(max(hid2 // 2, 2 * C))),
             "q": z(B, N, _r8(C)), "kv": z(B, N, _r8(2 * C)), "ao": z(B, N, _r8(C)),
             "fb": z(B, N, 64),
-            "gap": z(B, ops.layernorm_blocks(), 16, dtype=f),
+            "gap": z(B, max(ops.layernorm_blocks(), -(-H // 4) * -(-W // 16)), 16, dtype=f),
             "scale": z(B, 256, dtype=f), "eca_tmp": z(B, 32, 256, dtype=f),
         }
         esc0 = self.layers[0]["habs"][0]["esc"] if self.layers and self.layers[0]["habs"] else None
@@ -195,11 +202,11 @@ class HATEngine:
         return w
 
     # ------------------------------------------------------------------------------------------
-    def _esc_lk(self, esc: _ESC, w, n, B, H, W):
+    def _esc_lk(self, esc: _ESC, w, n, B, H, W, nblk):
         """ESC large-kernel + dynamic depthwise conv on the first pdim channels of `n` -> w['y16']."""
         dt, C = self.dtype, self.C
         N = H * W
-        ops.esc_weights(w["gap"], ops.layernorm_blocks(), N, esc.w1, esc.b1, esc.w2, esc.b2, esc.plk, w["weff"], B=B,
+        ops.esc_weights(w["gap"], nblk, N, esc.w1, esc.b1, esc.w2, esc.b2, esc.plk, w["weff"], B=B,
                         pdim=esc.pdim, ksize=esc.ksize, kpad=esc.kpad, dtype=dt)
         pw = ops.PackedConv(w["weff"], esc.zero_bias, esc.ksize, esc.pdim, esc.kpad, 1, 1, esc.pdim,
                             w_bstride=16 * esc.kpad)
@@ -230,53 +237,66 @@ class HATEngine:
         # (x - mean) * img_range ; conv_first                                           :849-853
         ops.conv(self.conv_first, x, w["f0"], **geo, ldx=0, ldo=C, x_mode=X_NCHW_F32_MEAN, out_mode=O_NHWC_F32,
                  in_scale=r, mean=mean)
-        tA, tB = w["tA"], w["tB"]
+        tA, tB, tC = w["tA"], w["tB"], w["tC"]
         if self.pe_norm is not None:  # patch_embed + LN                                 :836
             ln(w["f0"], tA, self.pe_norm, out_f32=True)
         else:
             tA.copy_(w["f0"])
+        LNB = ops.layernorm_blocks()
         for L in self.layers:
+            t = tA            # current value of the residual stream (tA must survive until the RHAG tail)
+            have_n = False    # w["n"] already holds the next LayerNorm of t (emitted by the fused FFN)
+            nblk = LNB        # number of GAP partial blocks currently in w["gap"]
+            oc = L["ocab"]
             for i, hb in enumerate(L["habs"]):  # HAB                                     :217-238
-                tin = tA if i == 0 else tB
                 esc = hb["esc"]
-                ln(tin, w["n"], hb["n1"], gap_c=esc.pdim)
+                if not have_n:
+                    ln(t, w["n"], hb["n1"], gap_c=esc.pdim)
+                    nblk = LNB
                 mid = hb["cab0"].nout
                 ops.conv(hb["cab0"], w["n"], w["c1"], **geo, ldx=ldc, ldo=_r8(mid), act=ACT_GELU, n_store=_r4(mid))
                 ops.conv(hb["cab2"], w["c1"], w["c2"], **geo, ldx=_r8(mid), ldo=ldc, colsum=w["colsum"])
                 ops.eca_scale(w["colsum"], w["tiles"], hb["cab2"].npad, N, hb["eca_w"], hb["eca_w"].numel(),
                               float(cfg["conv_scale"]), w["eca_tmp"], w["scale"], B=B, C_=C)
-                self._esc_lk(esc, w, w["n"], B, H, W)
+                self._esc_lk(esc, w, w["n"], B, H, W, nblk)
                 # t = t + aggr(cat(y16, n[pdim:])) + conv_scale * eca * c2                :236
                 ops.conv(esc.aggr, w["n"], tB, **geo, ldx=ldc, ldo=C, out_mode=O_NHWC_F32, x0=w["y16"], c_split=esc.pdim,
-                         ldx0=16, r1=tin, ldr1=C, r2=w["c2"], ldr2=ldc, r2scale=w["scale"], r2scale_bstride=hb["cab2"].npad)
-                ln(tB, w["n"], hb["n2"])
-                hid2 = hb["fc1"].nout
-                ops.conv(hb["fc1"], w["n"], w["u"], **geo, ldx=ldc, ldo=w["u"].shape[2])
-                ops.dwconv_gate(w["u"], hb["dw_w"], hb["dw_b"], w["g"], B=B, H=H, W=W, hid=hid2 // 2, ldu=w["u"].shape[2],
-                                ldo=w["g"].shape[2], dtype=dt)
-                ops.conv(hb["fc2"], w["g"], tB, **geo, ldx=w["g"].shape[2], ldo=C, out_mode=O_NHWC_F32, r1=tB, ldr1=C)
-            t = tB if L["habs"] else tA
-            oc = L["ocab"]  # OCAB                                                         :326-393
-            esc = oc.get("esc")
-            ln(t, w["n"], oc["n1"], gap_c=(esc.pdim if esc else 0))
+                         ldx0=16, r1=t, ldr1=C, r2=w["c2"], ldr2=ldc, r2scale=w["scale"], r2scale_bstride=hb["cab2"].npad)
+                if "ffn" in hb:  # fused LN2 + fc1 + dw3x3 + gate + fc2 + residual (+ the next block's LayerNorm)
+                    if i + 1 < len(L["habs"]):
+                        nxt, gap_c = L["habs"][i + 1]["n1"], L["habs"][i + 1]["esc"].pdim
+                    else:
+                        nxt, gap_c = oc["n1"], (oc["esc"].pdim if "esc" in oc else 0)
+                    ops.ffn(hb["ffn"], tB, tC, hb["n2"][0], hb["n2"][1], B=B, H=H, W=W, dtype=dt, ln1=nxt, n_out=w["n"],
+                            ldn=ldc, gap_out=w["gap"], gap_c=gap_c)
+                    t, have_n, nblk = tC, True, ops.ffn_tiles(hb["ffn"], H, W, dt)
+                else:
+                    ln(tB, w["n"], hb["n2"])
+                    hid2 = hb["fc1"].nout
+                    ops.conv(hb["fc1"], w["n"], w["u"], **geo, ldx=ldc, ldo=w["u"].shape[2])
+                    ops.dwconv_gate(w["u"], hb["dw_w"], hb["dw_b"], w["g"], B=B, H=H, W=W, hid=hid2 // 2, ldu=w["u"].shape[2],
+                                    ldo=w["g"].shape[2], dtype=dt)
+                    ops.conv(hb["fc2"], w["g"], tB, **geo, ldx=w["g"].shape[2], ldo=C, out_mode=O_NHWC_F32, r1=tB, ldr1=C)
+                    t, have_n = tB, False
+            esc = oc.get("esc")  # OCAB                                                    :326-393
+            if not have_n:
+                ln(t, w["n"], oc["n1"], gap_c=(esc.pdim if esc else 0))
+                nblk = LNB
             kv_src = w["n"]
             if esc is not None:  # K/V from ESC(LN(x))                                     :336-344
-                self._esc_lk(esc, w, w["n"], B, H, W)
+                self._esc_lk(esc, w, w["n"], B, H, W, nblk)
                 ops.conv(esc.aggr, w["n"], w["yesc"], **geo, ldx=ldc, ldo=ldc, x0=w["y16"], c_split=esc.pdim, ldx0=16)
                 kv_src = w["yesc"]
             ops.conv(oc["q"], w["n"], w["q"], **geo, ldx=ldc, ldo=ldc)
             ops.conv(oc["kv"], kv_src, w["kv"], **geo, ldx=ldc, ldo=w["kv"].shape[2])
             ops.ocab_attention(w["q"], w["kv"], oc["bias_rot"], w["ao"], B=B, H=H, W=W, C_=C, heads=L["heads"], ws=ws,
                                wse=self.wse, ldq=ldc, ldkv=w["kv"].shape[2], ldo=ldc, dtype=dt)
-            tout = tB if L["habs"] else tA
+            tout = tB if t is tA else t  # never write the RHAG input buffer
             ops.conv(oc["proj"], w["ao"], tout, **geo, ldx=ldc, ldo=C, out_mode=O_NHWC_F32, r1=t, ldr1=C)
             ln(tout, w["n"], oc["n2"])
             ops.conv(oc["mlp0"], w["n"], w["g"], **geo, ldx=ldc, ldo=w["g"].shape[2], act=ACT_GELU)
             ops.conv(oc["mlp2"], w["g"], tout, **geo, ldx=w["g"].shape[2], ldo=C, out_mode=O_NHWC_F32, r1=tout, ldr1=C)
-            # RHAG tail: conv3x3 + group residual                                          :556
-            if tout is tA:  # no HAB in this group: the conv must not read the buffer it writes
-                tB.copy_(tA)
-                tout = tB
+            # RHAG tail: conv3x3 + group residual, written over the group input             :556
             ops.conv(L["conv"], tout, tA, **geo, ldx=C, ldo=C, x_mode=X_NHWC_F32, out_mode=O_NHWC_F32, r1=tA, ldr1=C)
         ln(tA, w["n"], self.norm)  # final LN                                             :844
         # conv_after_body + f0 ; conv_before_upsample + LeakyReLU                          :854-855

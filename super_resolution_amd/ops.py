@@ -11,7 +11,7 @@ import torch
 
 from . import _lib
 from ._lib import (ACT_GELU, ACT_LRELU, ACT_NONE, HAT_BF16, HAT_F32, O_NCHW_F32, O_NHWC_F32, O_NHWC_T, O_PIXSHUF_T,
-                   X_NCHW_F32_MEAN, X_NHWC_F32, X_NHWC_T, HatConvDesc)
+                   X_NCHW_F32_MEAN, X_NHWC_F32, X_NHWC_T, HatConvDesc, HatFfnDesc)
 
 TORCH_DTYPE = {HAT_F32: torch.float32, HAT_BF16: torch.bfloat16}
 DTYPE_CODE = {"f32": HAT_F32, "fp32": HAT_F32, "float32": HAT_F32, "bf16": HAT_BF16, "bfloat16": HAT_BF16}
@@ -202,3 +202,107 @@ def ocab_attention(q, kv, bias_rot, out, *, B: int, H: int, W: int, C_: int, hea
     _timed(f"ocab_attn_kernel<{_TNAME[dtype]}>", 2.0 * 2 * wse * wse * C_ * B * H * W, lambda: _lib.check(
         lib.hat_ocab_attention(_ptr(q), _ptr(kv), _ptr(bias_rot), _ptr(out), B, H, W, C_, heads, ws, wse, ldq, ldkv, ldo, dtype,
                                _stream()), "hat_ocab_attention"))
+
+
+# ------------------------------------------------------------------------------------------------
+# fused feed-forward half of the HAB (hat_ffn)
+# ------------------------------------------------------------------------------------------------
+class PackedFFN:
+    __slots__ = ("w1f", "b1", "dww", "dwb", "w2f", "b2", "chunks", "C", "hid", "nt", "ks", "khalf")
+
+
+def ffn_supported(C_: int) -> bool:
+    """Shapes hat_ffn is instantiated for (anything else uses the unfused kernels)."""
+    return C_ in (144, 180) or (C_ <= 32 and C_ % 32 != 16 and C_ >= 8)
+
+
+def pack_ffn(fc1_w, fc1_b, dw_w, dw_b, fc2_w, fc2_b, dtype: int, device) -> PackedFFN:
+    """Fragment-pack GatedDconvFFN weights (hat_arch.py:99-104) for hat_ffn; layouts in include/hat_mi355x.h."""
+    f = lambda t: t.detach().to(torch.float32).cpu()
+    W1, b1, Wd, bd, W2, b2 = f(fc1_w), f(fc1_b), f(dw_w).reshape(-1, 9), f(dw_b), f(fc2_w), f(fc2_b)
+    C_, hid = W2.shape
+    assert W1.shape == (2 * hid, C_) and Wd.shape[0] == 2 * hid
+    chunks = -(-hid // 32)
+    hid_p = 32 * chunks
+    khalf = C_ % 32 == 16
+    ks = C_ // 32 + 1 if khalf else -(-C_ // 32)
+    nt = 9 if C_ == 144 else (12 if C_ == 180 else 2)
+    tdt = TORCH_DTYPE[dtype]
+    lane = torch.arange(64)
+    n16, g4 = lane & 15, lane >> 4
+    j8 = torch.arange(8)
+    # ---- fc1: w1f[chunk][nt4][ks][lane][8]
+    W1p = torch.zeros(2 * hid_p + 1, ks * 32 + 32)  # padded copy; last row = zeros for invalid rows
+    W1p[:hid, :C_] = W1[:hid]
+    W1p[hid_p:hid_p + hid, :C_] = W1[hid:]
+    c_i = torch.arange(chunks)[:, None, None, None, None]
+    nt_i = torch.arange(4)[None, :, None, None, None]
+    ks_i = torch.arange(ks)[None, None, :, None, None]
+    nl = nt_i * 16 + n16[None, None, None, :, None]                       # chunk-local channel 0..63
+    row = torch.where(nl < 32, c_i * 32 + nl, hid_p + c_i * 32 + (nl - 32))
+    kfull = ks_i * 32 + 8 * g4[None, None, None, :, None] + j8[None, None, None, None, :]
+    col = kfull.expand(chunks, 4, ks, 64, 8).clone()
+    row = row.expand(chunks, 4, ks, 64, 8)
+    w1f = W1p[row, col]
+    if khalf:  # last k-step is 16 deep: element j<4 <-> k = 32*(ks-1) + 4*g + j, elements 4..7 unused
+        khcol = (ks - 1) * 32 + 4 * g4[:, None] + j8[None, :4]             # (64, 4)
+        last = W1p[row[:, :, ks - 1, :, :4], khcol[None, None].expand(chunks, 4, 64, 4)]
+        w1f[:, :, ks - 1] = 0
+        w1f[:, :, ks - 1, :, :4] = last
+    # ---- fc2: w2f[chunk][nt][lane][8]
+    W2p = torch.zeros(nt * 16, hid_p)
+    W2p[:C_, :hid] = W2
+    n_i = (torch.arange(nt)[:, None] * 16 + n16[None, :])                  # (nt, 64)
+    k_i = torch.arange(chunks)[:, None, None] * 32 + 8 * g4[None, :, None] + j8[None, None, :]  # (chunks, 64, 8)
+    w2f = W2p[n_i[None, :, :, None].expand(chunks, nt, 64, 8), k_i[:, None].expand(chunks, nt, 64, 8)]
+    # ---- biases
+    b1p = torch.zeros(2 * hid_p)
+    b1p[:hid], b1p[hid_p:hid_p + hid] = b1[:hid], b1[hid:]
+    dwb = torch.zeros(2 * hid_p)
+    dwb[:hid], dwb[hid_p:hid_p + hid] = bd[:hid], bd[hid:]
+    b2p = torch.zeros(nt * 16)
+    b2p[:C_] = b2
+    # ---- depthwise weights
+    Wdp = torch.zeros(2, hid_p, 9)
+    Wdp[0, :hid], Wdp[1, :hid] = Wd[:hid], Wd[hid:]
+    if dtype == HAT_BF16:  # [chunk][octet 4][tap 9][half 2][8 pairs]: pair 2p = (w[c0+2p], 0), pair 2p+1 = (0, w[c0+2p+1])
+        wd = Wdp.reshape(2, chunks, 4, 8, 9).permute(1, 2, 4, 0, 3)          # (chunks, 4, 9, 2, 8 channels)
+        dww = torch.zeros(chunks, 4, 9, 2, 8, 2)
+        dww[..., 0::2, 0] = wd[..., 0::2]
+        dww[..., 1::2, 1] = wd[..., 1::2]
+        dww = dww.to(torch.bfloat16)
+    else:                   # [chunk][quad 8][tap 9][half 2][4]
+        dww = Wdp.reshape(2, chunks, 8, 4, 9).permute(1, 2, 4, 0, 3).contiguous()
+    p = PackedFFN()
+    p.w1f, p.w2f = w1f.to(tdt).contiguous().to(device), w2f.to(tdt).contiguous().to(device)
+    p.b1, p.dwb, p.b2 = b1p.to(device), dwb.to(device), b2p.to(device)
+    p.dww = dww.contiguous().to(device)
+    p.chunks, p.C, p.hid, p.nt, p.ks, p.khalf = chunks, C_, hid, nt, ks, khalf
+    return p
+
+
+def _ffn_desc(pf: PackedFFN, B, H, W, dtype):
+    d = HatFfnDesc()
+    d.B, d.H, d.W, d.C, d.chunks, d.dtype = B, H, W, pf.C, pf.chunks, dtype
+    return d
+
+
+def ffn_tiles(pf: PackedFFN, H: int, W: int, dtype: int) -> int:
+    lib = _lib.load()
+    d = _ffn_desc(pf, 1, H, W, dtype)
+    n = C.c_int32(0)
+    _lib.check(lib.hat_ffn_tiles(C.byref(d), C.byref(n)), "hat_ffn_tiles")
+    return n.value
+
+
+def ffn(pf: PackedFFN, t_in, t_out, ln_g, ln_b, *, B: int, H: int, W: int, dtype: int, ln1=None, n_out=None, ldn: int = 0,
+        gap_out=None, gap_c: int = 0):
+    lib = _lib.load()
+    d = _ffn_desc(pf, B, H, W, dtype)
+    d.t_in, d.t_out, d.ln_g, d.ln_b = _ptr(t_in), _ptr(t_out), _ptr(ln_g), _ptr(ln_b)
+    d.w1f, d.b1, d.dww, d.dwb, d.w2f, d.b2 = _ptr(pf.w1f), _ptr(pf.b1), _ptr(pf.dww), _ptr(pf.dwb), _ptr(pf.w2f), _ptr(pf.b2)
+    if ln1 is not None:
+        d.ln1_g, d.ln1_b, d.n_out, d.ldn = _ptr(ln1[0]), _ptr(ln1[1]), _ptr(n_out), ldn
+        d.gap_out, d.gap_c = (_ptr(gap_out) if gap_c else None), gap_c
+    flops = B * H * W * (2.0 * pf.C * 2 * pf.hid + 2.0 * 9 * 2 * pf.hid + 2.0 * pf.hid * pf.C)
+    _timed(f"ffn_kernel<{_TNAME[dtype]}>", flops, lambda: _lib.check(lib.hat_ffn(C.byref(d), _stream()), "hat_ffn"))

@@ -342,3 +342,56 @@ def test_esc_weights_and_eca(dtype, pdim, ks):
     ops.eca_scale(cs.to(dev), tiles, ldc, N, wk.to(dev), 5, 0.01, torch.zeros(B, 32, ldc, device=dev), scale, B=B, C_=C)
     torch.cuda.synchronize()
     check(scale[:, :C], ref, "f32", "eca scale", f32_tol=1e-6)
+
+
+# ------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("dtype", DT)
+@pytest.mark.parametrize("geom", [(144, 2, 40, 48), (180, 1, 24, 32), (24, 1, 13, 21)], ids=["C144", "C180", "C24"])
+def test_fused_ffn(dtype, geom):
+    """hat_ffn: t + fc2(a*silu(g)), [a|g] = dw3x3(fc1(LN2(t))) in one kernel, plus the fused NEXT LayerNorm and
+    its GAP partials, against the oracle's GatedDconvFFN restatement (hat_arch.py:107-119,237)."""
+    C, B, H, W = geom
+    dev, ops = _dev(), _ops()
+    dt = ops.DTYPE_CODE[dtype]
+    tdt = ops.TORCH_DTYPE[dt]
+    hid = 2 * C
+    t = rnd("ft", (B, H * W, C), std=1.5) + 0.3
+    sd = {
+        "n2.weight": 1 + rnd("fg", (C,), std=0.1), "n2.bias": rnd("fbb", (C,), std=0.1),
+        "m.fc1.weight": q(rnd("f1w", (2 * hid, C), std=C ** -0.5), dtype), "m.fc1.bias": rnd("f1b", (2 * hid,), std=0.1),
+        "m.dw.weight": q(rnd("fdw", (2 * hid, 1, 3, 3), std=1 / 3), dtype), "m.dw.bias": rnd("fdb", (2 * hid,), std=0.1),
+        "m.fc2.weight": q(rnd("f2w", (C, hid), std=hid ** -0.5), dtype), "m.fc2.bias": rnd("f2b", (C,), std=0.1),
+        "n1.weight": 1 + rnd("fg1", (C,), std=0.1), "n1.bias": rnd("fb1", (C,), std=0.1),
+    }
+    sdd = {k: v.double() for k, v in sd.items()}
+    ref = t.double() + O.gated_dconv_ffn(O._ln(t.double(), sdd, "n2"), (H, W), sdd, "m")
+    ref_n = O._ln(ref, sdd, "n1")
+    pf = ops.pack_ffn(sd["m.fc1.weight"], sd["m.fc1.bias"], sd["m.dw.weight"], sd["m.dw.bias"], sd["m.fc2.weight"],
+                      sd["m.fc2.bias"], dt, dev)
+    tin = t.to(dev).contiguous()
+    tout = torch.full_like(tin, 123.0)
+    ld = _r8(C)
+    nout = torch.zeros(B, H * W, ld, dtype=tdt, device=dev)
+    tiles = ops.ffn_tiles(pf, H, W, dt)
+    gap = torch.zeros(B, tiles, 16, device=dev)
+    gap_c = 16 if C >= 16 else 8
+    dv = lambda k: sd[k].to(dev).contiguous()
+    ops.ffn(pf, tin, tout, dv("n2.weight"), dv("n2.bias"), B=B, H=H, W=W, dtype=dt, ln1=(dv("n1.weight"), dv("n1.bias")),
+            n_out=nout, ldn=ld, gap_out=gap, gap_c=gap_c)
+    torch.cuda.synchronize()
+    if dtype == "f32":
+        check(tout, ref, dtype, "fused ffn", f32_tol=3e-5)
+        check(nout[:, :, :C].float(), ref_n, dtype, "fused next-LN", f32_tol=3e-5)
+    else:
+        # the hidden tensor is rounded to bf16 twice (u and a*silu(g)); judge the FFN update itself
+        upd, upd_ref = (tout.double().cpu() - t.double()), (ref - t.double())
+        rel = float((upd - upd_ref).norm() / upd_ref.norm())
+        assert rel <= 1.5e-2, f"fused ffn update rel err {rel:.3e}"
+        check(nout[:, :, :C].float(), ref_n, dtype, "fused next-LN")
+    check(gap.sum(1)[:, :gap_c] / (H * W), ref_n[:, :, :gap_c].mean(1), "f32", "fused gap partials",
+          f32_tol=(1e-5 if dtype == "f32" else 2e-3))
+    # without the fused LN
+    tout2 = torch.zeros_like(tin)
+    ops.ffn(pf, tin, tout2, dv("n2.weight"), dv("n2.bias"), B=B, H=H, W=W, dtype=dt)
+    torch.cuda.synchronize()
+    assert torch.equal(tout, tout2)
