@@ -167,7 +167,7 @@ def main():
     # ---- per-kernel timing with HIP events on the launch stream (rank 0) -------------------------
     roofline, kernels = None, None
     if rank == 0 and not args.no_kernel_profile:
-        agg = {}
+        agg, layers = {}, {}
         reps = 2
         for _ in range(reps):
             with ops.profile() as rec:
@@ -176,15 +176,25 @@ def main():
                 else:
                     tp.run_tile(x, net, tiles[tp.assign(tiles, world)[0][0]], s)
                 torch.cuda.synchronize()
-                for name, fl, a, b in rec:
+                for name, fl, a, b, tag in rec:
+                    ms = a.elapsed_time(b)
                     e = agg.setdefault(name, [0, 0.0, 0.0])
                     e[0] += 1
-                    e[1] += a.elapsed_time(b)
+                    e[1] += ms
                     e[2] += fl
+                    if tag:
+                        e2 = layers.setdefault(name + " | " + tag, [0, 0.0, 0.0])
+                        e2[0] += 1
+                        e2[1] += ms
+                        e2[2] += fl
         total_ms = sum(e[1] for e in agg.values())
         kernels = {k: {"launches_per_step": e[0] // reps, "avg_ms": round(e[1] / e[0], 4), "share": round(e[1] / total_ms, 4),
                        "tflops": round(e[2] / (e[1] * 1e-3) / 1e12, 2) if e[2] else None}
                    for k, e in sorted(agg.items(), key=lambda kv: -kv[1][1])}
+        if os.environ.get("HAT_BENCH_LAYERS"):
+            for k, e2 in sorted(layers.items(), key=lambda kv: -kv[1][1]):
+                print(f"# {e2[1] / reps:8.3f} ms/step  {e2[0] // reps:3d}x {e2[1] / e2[0]:7.4f} ms  "
+                      f"{e2[2] / (e2[1] * 1e-3) / 1e12 if e2[2] else 0:7.1f} TF  {k}", file=sys.stderr)
         dom, e = max(agg.items(), key=lambda kv: kv[1][1])
         achieved = e[2] / (e[1] * 1e-3) / 1e12
         peak = MFMA_PEAK_TFLOPS[args.dtype]

@@ -142,11 +142,15 @@ int hat_ocab_attention(const void* q, const void* kv, const float* bias_rot, voi
  * write of the fp32 residual stream.  Optionally also emits the NEXT block's LayerNorm of t_out
  * (n_out, T) and its ESC global-average-pool partials (gap_out[b][tile][16]), saving that pass.
  * t_out must not alias t_in (3x3 halo).  Weights are "fragment packed" by the host:
- *   w1f [chunk][4][KS][64 lanes][8]  : fc1 rows {a: 32c..32c+31, g: hid_p+32c..} of chunk c, MFMA A-fragment order
- *   w2f [chunk][nt][64 lanes][8]     : fc2 columns 32c..32c+31
- *   dww : depthwise weights, bf16: [chunk][4 octets][9 taps][a|g][8 dwords = (w,0),(0,w) bf16 pairs]
- *                            f32 : [chunk][8 quads][9 taps][a|g][4 floats]
- *   b1, dwb : [2*hid_p] fp32 (a-part then g-part), b2 : [nt*16] fp32; hid_p = 32*chunks >= hidden, zero padded.
+ *   w1f [chunk][4][KS][64 lanes][8]  : fc1 rows {a: 32c..32c+31, g: hid_p+32c..} of chunk c, MFMA A-fragment order,
+ *                                      K = round_up(C+1, 32) with the fc1 BIAS stored as column k = C
+ *   w2f [chunk][nt][64 lanes][8]     : fc2 columns 32c..32c+31, k order (g, j<4) -> 4g+j, (g, j>=4) -> 16+4g+j-4
+ *   dww [chunk][64 lanes][4 groups x 5 tap pairs] (fp32, or a bf16 duplicated in both halves of a dword): the
+ *        depthwise weight of channel (lane & 15) of each 16-channel group {a0, a1, g0, g1} for tap
+ *        2*pair + (lane >> 5) — "tap 9" is the depthwise BIAS — zero in lanes with
+ *        ((lane & 15) >> 3) != ((lane >> 4) & 1); the kernel expands it to a diagonal MFMA operand
+ *   b2 : [nt*16] fp32; hid_p = 32*chunks >= hidden, zero padded.  (b1, dwb: [2*hid_p] fp32 copies of the biases
+ *   that are folded into w1f / dww; kept for reference, not read by the kernel.)
  * Spatial tile = (2*waves) rows x 16 columns; hat_ffn_tiles() returns the tile count (leading dim of gap_out).
  */
 typedef struct HatFfnDesc {

@@ -10,7 +10,7 @@ import os
 import threading
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libhat_mi355x.so")
+LIB_PATH = os.environ.get("HAT_MI355X_LIB") or os.path.join(_HERE, "libhat_mi355x.so")  # env override: A/B builds
 
 HAT_F32, HAT_BF16 = 0, 1
 ACT_NONE, ACT_GELU, ACT_LRELU = 0, 1, 2

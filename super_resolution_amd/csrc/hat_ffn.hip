@@ -3,67 +3,84 @@
 // reference: hat/archs/hat_arch.py:237 (x + mlp(norm2(x))) with GatedDconvFFN.forward :107-119.
 //
 // One workgroup = WAVES waves = a (2*WAVES) x 16 pixel tile.  The 4C-wide hidden tensor (the
-// reference materialises it twice in HBM: 1-6 GB) lives only in LDS, 32 (+32 gate) channels at a time:
+// reference materialises it twice in HBM: 1-6 GB) lives only on chip, 32 (+32 gate) channels at a time:
 //
-//   stage 0   LN2 of the haloed (rows+2) x 18 input tile, fp32 stats            -> Ms[pix][C]     (T)
+//   stage 0   LN2 of the haloed (rows+2) x 18 input tile, fp32 stats; column C of every in-image
+//             row is 1.0 so that the fc1 bias is one more k (out-of-image rows are all zero, hence
+//             U = 0 there: the depthwise conv zero-pads u AFTER the fc1 bias)       -> Ms[pix][Kp]  (T, LDS)
 //   per chunk c of 32 hidden channels (a-part) + their 32 gate channels:
-//     fc1     U = Ms . W1[chunk]^T + b1 on ALL haloed pixels (MFMA), 0 outside the image (the
-//             depthwise conv zero-pads u, AFTER the fc1 bias)                    -> Us[pix][64]    (T)
-//     dw      depthwise 3x3 + bias on the tile's own pixels, a * SiLU(g) (VALU; lane = pixel,
-//             wave-uniform channel group => weights come from SGPRs)             -> Gs[pix][32]    (T)
-//     fc2     acc[C][pix] += W2[:, chunk] . Gs^T  (MFMA, accumulators live in registers across chunks)
+//     fc1     U = Ms . [W1[chunk] | b1]^T on ALL haloed pixels (MFMA)               -> Us[pix][64]  (T, LDS)
+//     dw      depthwise 3x3 as MFMA: D[ch][pix] += diag(w_tap) . U_tap, two taps per 32-deep k-step
+//             (A = [diag(w_t0) | diag(w_t1)] built in registers from one per-lane weight, B = the
+//             shifted pixels' 16 channels read from Us); the 10th "tap" multiplies a constant 1 by
+//             the depthwise bias.                                                          (registers)
+//     gate    a * SiLU(g) on the accumulators; because D has channels on the accumulator-row index,
+//             the product is already the B operand of fc2 (k order permuted identically in W2)
+//     fc2     acc[C][pix] += W2[:, chunk] . G   (MFMA; accumulators persist across chunks)
 //   epilogue  t_out = t_in + acc + b2 ; optionally the NEXT LayerNorm of t_out and its GAP partials.
 //
 // Weights never touch LDS: they are fragment-packed on the host, so a wave's A operand is ONE
-// coalesced 1 KiB global load (L1/L2 resident).  Us / Gs rows are exact powers of two and are
-// XOR-swizzled per 16-byte slot instead of padded (LDS is full: 156 KiB at C = 144, bf16).
+// coalesced 1 KiB global load (L1/L2 resident), issued a stage ahead of its use.  Each wave runs dw,
+// gate and fc2 on its OWN two tile rows, so only U crosses waves (2 barriers per chunk).
 #include "hat_common.h"
+
+#include <type_traits>
 
 namespace {
 
 constexpr int CH = 32;        // hidden channels per chunk (a-part); the chunk also carries CH gate channels
 constexpr int HALO_W = 18;    // 16 + 2
+constexpr int NPAIR = 5;      // 9 taps, two per k-step
 
-template <typename T> struct Q16 { static constexpr int N = 16 / sizeof(T); T v[16 / sizeof(T)]; } __attribute__((aligned(16)));
-
-// swizzled element offset inside a [rows][NS slots of 16 bytes] LDS array with NS a power of two <= 16
+// swizzled 16-byte slot inside a [rows][NS slots] LDS array, NS a power of two <= 16
 template <int NS> __device__ __forceinline__ int swz_slot(int row, int slot) {
     constexpr int R = 16 / NS;  // rows per 256-byte bank row
     return slot ^ ((row / R) & (NS - 1));
 }
 
-__host__ __device__ inline int ffn_kp(int C) { return (C % 32 == 16) ? C : ((C + 31) & ~31); }
-
-template <typename T, int WAVES>
-__host__ __device__ inline size_t ffn_lds_bytes(int C) {
-    const int nph = (2 * WAVES + 2) * HALO_W;
-    const size_t ms = (size_t)nph * lds_row_elems(ffn_kp(C), sizeof(T)) * sizeof(T);
-    const size_t us = (size_t)nph * 2 * CH * sizeof(T);
-    const size_t gs = (size_t)2 * WAVES * 16 * CH * sizeof(T);
-    return ms + us + gs;
+// K of fc1 padded to a multiple of 32 with room for the bias column at k = C
+__host__ __device__ inline int ffn_kp(int C) { return (C + 1 + 31) & ~31; }
+// Ms row stride: MSWZ = unpadded rows + XOR swizzle (rows of 4 (mod 8) slots, e.g. 160 bf16), else odd-slot padding
+template <typename T, bool MSWZ> __host__ __device__ inline int ffn_ldm(int C) {
+    return MSWZ ? ffn_kp(C) : lds_row_elems(ffn_kp(C), sizeof(T));
 }
 
-template <typename T, int WAVES, int NT, int KS, bool KHALF>
+template <typename T, int WAVES, bool MSWZ>
+__host__ __device__ inline size_t ffn_lds_bytes(int C) {
+    const int nph = (2 * WAVES + 2) * HALO_W;
+    const size_t ms = (size_t)nph * ffn_ldm<T, MSWZ>(C) * sizeof(T);
+    const size_t us = (size_t)(nph + 1) * 2 * CH * sizeof(T);  // + the constant-one row (depthwise bias)
+    return ms + us;
+}
+
+__device__ __forceinline__ float silu_fast(float x) { return x * __builtin_amdgcn_rcpf(1.0f + __expf(-x)); }
+__device__ __forceinline__ float silu_exact(float x) { return x / (1.0f + expf(-x)); }
+
+// DBG is a timing-ablation mask used only by tools/ubench_ffn.hip (the library instantiates DBG = 0):
+//   1 skip LN stage, 2 skip fc1 MFMA loop, 4 skip the dw MFMAs, 8 skip gate math, 16 skip fc2 MFMAs,
+//   32 skip all weight-fragment loads
+template <typename T, int WAVES, int NT, int KS, bool MSWZ, int DBG = 0>
 __global__ __launch_bounds__(WAVES * 64) void ffn_kernel(const HatFfnDesc d) {
     using M = MT<T>;
+    using frag_t = typename M::frag_t;
     constexpr int NTHR = WAVES * 64;
     constexpr int TROWS = 2 * WAVES;
     constexpr int NPH = (TROWS + 2) * HALO_W;     // haloed pixels
     constexpr int NPT = (NPH + 15) / 16;          // fc1 pixel tiles over the flattened halo tile
     constexpr int VECN = M::VEC;                  // elements per 16 bytes
-    constexpr int NOCT = CH / VECN;               // 16-byte channel groups per half-chunk
     constexpr int NSU = 2 * CH / VECN;            // 16-byte slots per Us row
-    constexpr int NSG = CH / VECN;                // 16-byte slots per Gs row
-    constexpr int PG = WAVES / 2;                 // fc1 pixel groups (each handled by 2 waves: a / g n-tile pairs)
+    constexpr int PG = WAVES / 2;                 // fc1 pixel groups (each handled by 2 waves: n-tile pairs)
     constexpr bool BF = sizeof(T) == 2;
+    constexpr int LNB = 4;                        // pixels per 16-lane group kept in flight in the LN stage
 
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int C = d.C;
     const int Kp = ffn_kp(C);
-    const int ldm = lds_row_elems(Kp, sizeof(T));
+    const int ldm = ffn_ldm<T, MSWZ>(C);
+    // 16-byte slot -> element offset inside an Ms row (swizzled when MSWZ: rows of 4 (mod 8) slots collide 4 apart)
+    auto ms_slot = [](int row, int slot) { return (MSWZ ? (slot ^ ((row >> 2) & 3)) : slot) * VECN; };
     T* Ms = reinterpret_cast<T*>(smem);
     T* Us = Ms + (size_t)NPH * ldm;
-    T* Gs = Us + (size_t)NPH * 2 * CH;
 
     const int tid = threadIdx.x, lane = tid & 63, g = lane >> 4, c16 = lane & 15;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -73,213 +90,267 @@ __global__ __launch_bounds__(WAVES * 64) void ffn_kernel(const HatFfnDesc d) {
     const int hid_p = d.chunks * CH;
 
     // ------------------------------ stage 0: LayerNorm2 -> Ms --------------------------------
-    {
+    if constexpr (!(DBG & 1)) {
         const int j = tid & 15, grp = tid >> 4;
+        constexpr int NGRP = NTHR / 16;
         const float invC = 1.0f / (float)C;
-        for (int hp = grp; hp < NPH; hp += NTHR / 16) {
-            const int hy = hp / HALO_W, hx = hp - hy * HALO_W;
-            const int y = y0 - 1 + hy, x = x0 - 1 + hx;
-            const bool inside = y >= 0 && y < H && x >= 0 && x < W;
-            f32x4 xv[3];
-            float s = 0.f;
+        for (int base = 0; base < NPH; base += NGRP * LNB) {
+            f32x4 xv[LNB][3];
+            bool inside[LNB];
 #pragma unroll
-            for (int v = 0; v < 3; ++v) {
-                const int c = 4 * j + 64 * v;
-                xv[v] = f32x4{0.f, 0.f, 0.f, 0.f};
-                if (inside && c < C) xv[v] = *reinterpret_cast<const f32x4*>(tin + ((size_t)y * W + x) * C + c);
-                s += (xv[v][0] + xv[v][1]) + (xv[v][2] + xv[v][3]);
-            }
-            s += __shfl_xor(s, 1); s += __shfl_xor(s, 2); s += __shfl_xor(s, 4); s += __shfl_xor(s, 8);
-            const float mean = s * invC;
-            float q = 0.f;
+            for (int u = 0; u < LNB; ++u) {  // issue all loads of LNB pixels first (latency), then reduce
+                const int hp = base + u * NGRP + grp;
+                const int hy = hp / HALO_W, hx = hp - hy * HALO_W;
+                const int y = y0 - 1 + hy, x = x0 - 1 + hx;
+                inside[u] = hp < NPH && y >= 0 && y < H && x >= 0 && x < W;
 #pragma unroll
-            for (int v = 0; v < 3; ++v) {
-                const int c = 4 * j + 64 * v;
-                if (c < C) {
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) { const float dl = xv[v][r] - mean; q += dl * dl; }
+                for (int v = 0; v < 3; ++v) {
+                    const int c = 4 * j + 64 * v;
+                    xv[u][v] = f32x4{0.f, 0.f, 0.f, 0.f};
+                    if (inside[u] && c < C) xv[u][v] = *reinterpret_cast<const f32x4*>(tin + ((size_t)y * W + x) * C + c);
                 }
             }
-            q += __shfl_xor(q, 1); q += __shfl_xor(q, 2); q += __shfl_xor(q, 4); q += __shfl_xor(q, 8);
-            const float rstd = 1.0f / sqrtf(q * invC + 1e-5f);
 #pragma unroll
-            for (int v = 0; v < 3; ++v) {
-                const int c = 4 * j + 64 * v;
-                if (c < Kp) {
-                    f32x4 o = {0.f, 0.f, 0.f, 0.f};
-                    if (inside && c < C) {
-                        const f32x4 gm = *reinterpret_cast<const f32x4*>(d.ln_g + c);
-                        const f32x4 bt = *reinterpret_cast<const f32x4*>(d.ln_b + c);
+            for (int u = 0; u < LNB; ++u) {
+                const int hp = base + u * NGRP + grp;
+                float s = 0.f;
 #pragma unroll
-                        for (int r = 0; r < 4; ++r) o[r] = (xv[v][r] - mean) * rstd * gm[r] + bt[r];
+                for (int v = 0; v < 3; ++v) s += (xv[u][v][0] + xv[u][v][1]) + (xv[u][v][2] + xv[u][v][3]);
+                s += __shfl_xor(s, 1); s += __shfl_xor(s, 2); s += __shfl_xor(s, 4); s += __shfl_xor(s, 8);
+                const float mean = s * invC;
+                float q = 0.f;
+#pragma unroll
+                for (int v = 0; v < 3; ++v) {
+                    if (4 * j + 64 * v < C) {
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) { const float dl = xv[u][v][r] - mean; q += dl * dl; }
                     }
-                    Vec4<T>::store(Ms + (size_t)hp * ldm + c, o);
+                }
+                q += __shfl_xor(q, 1); q += __shfl_xor(q, 2); q += __shfl_xor(q, 4); q += __shfl_xor(q, 8);
+                const float rstd = 1.0f / sqrtf(q * invC + 1e-5f);
+                if (hp < NPH) {
+#pragma unroll
+                    for (int v = 0; v < 3; ++v) {
+                        const int c = 4 * j + 64 * v;
+                        if (c < Kp) {
+                            f32x4 o = {0.f, 0.f, 0.f, 0.f};
+                            if (inside[u] && c < C) {
+                                const f32x4 gm = *reinterpret_cast<const f32x4*>(d.ln_g + c);
+                                const f32x4 bt = *reinterpret_cast<const f32x4*>(d.ln_b + c);
+#pragma unroll
+                                for (int r = 0; r < 4; ++r) o[r] = (xv[u][v][r] - mean) * rstd * gm[r] + bt[r];
+                            } else if (inside[u] && c == C) {
+                                o[0] = 1.0f;  // bias column (C % 4 == 0)
+                            }
+                            Vec4<T>::store(Ms + (size_t)hp * ldm + ms_slot(hp, c / VECN) + (c % VECN), o);
+                        }
+                    }
                 }
             }
         }
     }
-    __syncthreads();
 
     // persistent fc2 accumulators: this wave's two tile rows x all NT channel tiles
     f32x4 acc2[NT][2];
 #pragma unroll
-    for (int nt = 0; nt < NT; ++nt) { acc2[nt][0] = f32x4{0.f, 0.f, 0.f, 0.f}; acc2[nt][1] = acc2[nt][0]; }
+    for (int nt = 0; nt < NT; ++nt) { acc2[nt][0] = *reinterpret_cast<const f32x4*>(d.b2 + nt * 16 + 4 * (lane >> 4)); acc2[nt][1] = acc2[nt][0]; }
 
     const T* w1f = reinterpret_cast<const T*>(d.w1f);
     const T* w2f = reinterpret_cast<const T*>(d.w2f);
     const int nt2 = wave & 1, pg = wave >> 1;
+    const int jstar = c16 & 7;                          // position of this lane's channel inside its 8-wide k group
+    // bf16: dword masks that place the (duplicated) 16-bit weight at element jstar of an otherwise zero fragment
+    unsigned dmask[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) dmask[i] = (i == (jstar >> 1)) ? ((jstar & 1) ? 0xFFFF0000u : 0x0000FFFFu) : 0u;
+    using wdw_t = typename std::conditional<sizeof(T) == 2, unsigned, float>::type;
+    const wdw_t* dwl = reinterpret_cast<const wdw_t*>(d.dww);  // [chunk][lane][4 groups * NPAIR]
+
+    // fc1 weight fragments of the CURRENT chunk (loaded one chunk ahead, during the previous fc2)
+    frag_t a1[2][KS];
+    auto load_a1 = [&](int chunk) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks)
+                a1[i][ks] = (DBG & 32) ? M::zero() : M::load(w1f + ((((size_t)chunk * 4 + (2 * nt2 + i)) * KS + ks) * 64 + lane) * 8);
+    };
+    // B operand of fc1: the LayerNorm'ed pixels of one 16-pixel tile, all K
+    auto load_b = [&](int pt, frag_t (&bf)[KS]) {
+        int hpc = pt * 16 + c16;
+        hpc = hpc < NPH ? hpc : NPH - 1;
+        const T* mrow = Ms + (size_t)hpc * ldm;
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+            if constexpr (BF) {
+                bf[ks] = M::load(mrow + ms_slot(hpc, 4 * ks + g));
+            } else {
+                const f32x4 lo = *reinterpret_cast<const f32x4*>(mrow + ms_slot(hpc, 8 * ks + 2 * g));
+                const f32x4 hi = *reinterpret_cast<const f32x4*>(mrow + ms_slot(hpc, 8 * ks + 2 * g + 1));
+                bf[ks][0] = lo[0]; bf[ks][1] = lo[1]; bf[ks][2] = lo[2]; bf[ks][3] = lo[3];
+                bf[ks][4] = hi[0]; bf[ks][5] = hi[1]; bf[ks][6] = hi[2]; bf[ks][7] = hi[3];
+            }
+        }
+    };
+    // B operands of the depthwise stage for tap pair `pr`: [group][row] fragments of the shifted pixels.
+    // Lanes g >= 2 of pair 4 carry the BIAS "tap": they read the constant-one row NPH of Us.
+    auto load_u = [&](int pr, frag_t (&bf)[4][2]) {
+        const int tapr = 2 * pr + (g >> 1);
+        const int tap = tapr < 9 ? tapr : 8;
+        const int dy = (tap * 11) >> 5, dx = tap - 3 * dy;
+        const int hp0 = (2 * wave + dy) * HALO_W + c16 + dx;   // row 0 of this wave; row 1 is one halo row below
+#pragma unroll
+        for (int pt = 0; pt < 2; ++pt) {
+            const int hp = tapr < 9 ? hp0 + pt * HALO_W : NPH;
+            const T* urow = Us + (size_t)hp * 2 * CH;
+#pragma unroll
+            for (int gi = 0; gi < 4; ++gi) {
+                if constexpr (BF) {
+                    bf[gi][pt] = M::load(urow + swz_slot<NSU>(hp, 2 * gi + (g & 1)) * VECN);
+                } else {
+                    const f32x4 lo = *reinterpret_cast<const f32x4*>(urow + swz_slot<NSU>(hp, 4 * gi + 2 * (g & 1)) * VECN);
+                    const f32x4 hi = *reinterpret_cast<const f32x4*>(urow + swz_slot<NSU>(hp, 4 * gi + 2 * (g & 1) + 1) * VECN);
+                    bf[gi][pt][0] = lo[0]; bf[gi][pt][1] = lo[1]; bf[gi][pt][2] = lo[2]; bf[gi][pt][3] = lo[3];
+                    bf[gi][pt][4] = hi[0]; bf[gi][pt][5] = hi[1]; bf[gi][pt][6] = hi[2]; bf[gi][pt][7] = hi[3];
+                }
+            }
+        }
+    };
+    constexpr int NPTW = (NPT + PG - 1) / PG;  // fc1 pixel tiles per wave
+    using wdw4_t = wdw_t __attribute__((ext_vector_type(4)));
+
+    // constant-one row of Us (the depthwise bias is "tap 9" times 1)
+    for (int i = tid; i < 2 * CH; i += NTHR) Us[(size_t)NPH * 2 * CH + i] = to_T<T>(1.0f);
+    load_a1(0);
+    __syncthreads();  // Ms complete
 
     for (int chunk = 0; chunk < d.chunks; ++chunk) {
-        // ------------------------------------ fc1 -> Us ---------------------------------------
+        // ================================ phase A: fc1 -> Us ====================================
+        wdw_t wdw[4 * NPAIR];  // depthwise weights of this chunk: in flight during fc1
         {
-            typename M::frag_t a[2][KS];
+            const wdw4_t* wp = reinterpret_cast<const wdw4_t*>(dwl + ((size_t)chunk * 64 + lane) * (4 * NPAIR));
 #pragma unroll
-            for (int i = 0; i < 2; ++i)
+            for (int i = 0; i < NPAIR; ++i) {
+                const wdw4_t v = wp[i];
 #pragma unroll
-                for (int ks = 0; ks < KS; ++ks)
-                    a[i][ks] = M::load(w1f + ((((size_t)chunk * 4 + (2 * nt2 + i)) * KS + ks) * 64 + lane) * 8);
-            f32x4 bias[2];
-#pragma unroll
-            for (int i = 0; i < 2; ++i) {
-                const int nl = (2 * nt2 + i) * 16 + 4 * g;  // chunk-local channel 0..63: [0,32) a-part, [32,64) gate
-                const int gi = nl < CH ? chunk * CH + nl : hid_p + chunk * CH + (nl - CH);
-                bias[i] = *reinterpret_cast<const f32x4*>(d.b1 + gi);
+                for (int k = 0; k < 4; ++k) wdw[4 * i + k] = (DBG & 32) ? wdw_t(0) : v[k];
             }
-            for (int pt = pg; pt < NPT; pt += PG) {
-                const int hp = pt * 16 + c16;
-                const int hpc = hp < NPH ? hp : NPH - 1;
-                const T* mrow = Ms + (size_t)hpc * ldm;
+        }
+        {
+            frag_t bcur[KS], bnxt[KS];
+            load_b(pg, bcur);
+#pragma unroll
+            for (int i = 0; i < NPTW; ++i) {
+                const int pt = pg + i * PG;
+                if (i + 1 < NPTW) load_b(pt + PG, bnxt);  // next tile's operands are in flight during these MFMAs
                 f32x4 acc[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
 #pragma unroll
-                for (int ks = 0; ks < KS; ++ks) {
-                    if (KHALF && ks == KS - 1) {
-                        const typename M::half_t bh = M::load_half(mrow + ks * 32 + 4 * g);
+                for (int ks = 0; ks < ((DBG & 2) ? 0 : KS); ++ks) {
 #pragma unroll
-                        for (int i = 0; i < 2; ++i) {
-                            typename M::half_t ah;
-                            if constexpr (BF) {
-                                const typename M::frag_t f = a[i][ks];
-                                ah = *reinterpret_cast<const typename M::half_t*>(&f);
-                            } else {
-                                ah = f32x4{a[i][ks][0], a[i][ks][1], a[i][ks][2], a[i][ks][3]};
-                            }
-                            acc[i] = M::mma_half(ah, bh, acc[i]);
-                        }
-                    } else {
-                        const typename M::frag_t bf = M::load(mrow + ks * 32 + 8 * g);
-#pragma unroll
-                        for (int i = 0; i < 2; ++i) acc[i] = M::mma(a[i][ks], bf, acc[i]);
-                    }
+                    for (int ii = 0; ii < 2; ++ii) acc[ii] = M::mma(a1[ii][ks], bcur[ks], acc[ii]);
                 }
-                const int hy = hp / HALO_W, hx = hp - hy * HALO_W;
-                const int y = y0 - 1 + hy, x = x0 - 1 + hx;
-                const bool inside = hp < NPH && y >= 0 && y < H && x >= 0 && x < W;
-                if (hp < NPH) {
+                const int hp = pt * 16 + c16;
+                if (hp < NPH) {  // also false for the padding tiles pt >= NPT
 #pragma unroll
-                    for (int i = 0; i < 2; ++i) {
-                        const int nl = (2 * nt2 + i) * 16 + 4 * g;
-                        f32x4 v = {0.f, 0.f, 0.f, 0.f};
-                        if (inside) v = acc[i] + bias[i];
+                    for (int ii = 0; ii < 2; ++ii) {
+                        const int nl = (2 * nt2 + ii) * 16 + 4 * g;  // chunk-local channel: [0,32) a-part, [32,64) gate
                         const int slot = swz_slot<NSU>(hp, nl / VECN);
-                        Vec4<T>::store(Us + (size_t)hp * 2 * CH + slot * VECN + (nl % VECN), v);
+                        Vec4<T>::store(Us + (size_t)hp * 2 * CH + slot * VECN + (nl % VECN), acc[ii]);
+                    }
+                }
+                if (i + 1 < NPTW) {
+#pragma unroll
+                    for (int ks = 0; ks < KS; ++ks) bcur[ks] = bnxt[ks];
+                }
+            }
+        }
+        __syncthreads();  // Us complete
+
+        // ============ phase B: depthwise 3x3 as MFMA with diagonal weights (this wave's two rows) ============
+        f32x4 dacc[4][2];
+#pragma unroll
+        for (int gi = 0; gi < 4; ++gi) { dacc[gi][0] = f32x4{0.f, 0.f, 0.f, 0.f}; dacc[gi][1] = dacc[gi][0]; }
+        frag_t a2[NT];
+        {
+            frag_t bc[4][2], bn[4][2];
+            if constexpr (!(DBG & 4)) load_u(0, bc);
+#pragma unroll
+            for (int pr = 0; pr < NPAIR; ++pr) {
+                if constexpr (!(DBG & 4)) {
+                    if (pr + 1 < NPAIR) load_u(pr + 1, bn);
+                }
+                if (pr == NPAIR - 1) {  // fc2 weights: issued now, consumed after the gate math
+#pragma unroll
+                    for (int nt = 0; nt < NT; ++nt)
+                        a2[nt] = (DBG & 32) ? M::zero() : M::load(w2f + (((size_t)chunk * NT + nt) * 64 + lane) * 8);
+                }
+                if constexpr (!(DBG & 4)) {
+#pragma unroll
+                    for (int gi = 0; gi < 4; ++gi) {
+                        // A = [diag(w_tap0) | diag(w_tap1)]: this lane's row (channel c16 of the group) has ONE non-zero
+                        // element, at position jstar of its 8-wide k group (the host zeroes the weight in lanes whose k
+                        // group does not hold channel c16)
+                        frag_t af;
+                        if constexpr (BF) {
+                            u32x4 aw;
+#pragma unroll
+                            for (int i = 0; i < 4; ++i) aw[i] = wdw[gi * NPAIR + pr] & dmask[i];
+                            af = __builtin_bit_cast(frag_t, aw);
+                        } else {
+#pragma unroll
+                            for (int jj = 0; jj < 8; ++jj) af[jj] = (jj == jstar) ? wdw[gi * NPAIR + pr] : 0.f;
+                        }
+                        dacc[gi][0] = M::mma(af, bc[gi][0], dacc[gi][0]);
+                        dacc[gi][1] = M::mma(af, bc[gi][1], dacc[gi][1]);
+                    }
+                    if (pr + 1 < NPAIR) {
+#pragma unroll
+                        for (int gi = 0; gi < 4; ++gi) { bc[gi][0] = bn[gi][0]; bc[gi][1] = bn[gi][1]; }
                     }
                 }
             }
         }
-        __syncthreads();
-
-        // --------------------- depthwise 3x3 + bias, a * SiLU(g) -> Gs ------------------------
-        {
-            constexpr int NRGU = (TROWS + 7) / 8;
-            for (int u = wave; u < NOCT * NRGU; u += WAVES) {
-                const int oct = u % NOCT, hh = u / NOCT;       // wave-uniform
-                const int x = lane & 15, yr = hh * 8 + (lane >> 4) * 2;  // this lane's two output rows yr, yr+1
-                if (yr < TROWS) {
-                    const int ca = chunk * CH + oct * VECN;    // first a-part channel of this group (global index)
-                    float aA[2][VECN], aG[2][VECN];
-#pragma unroll
-                    for (int c = 0; c < VECN; ++c) {
-                        aA[0][c] = aA[1][c] = d.dwb[ca + c];
-                        aG[0][c] = aG[1][c] = d.dwb[hid_p + ca + c];
-                    }
-#pragma unroll
-                    for (int ry = 0; ry < 4; ++ry) {
-#pragma unroll
-                        for (int dx = 0; dx < 3; ++dx) {
-                            const int hp = (yr + ry) * HALO_W + x + dx;
-                            const T* urow = Us + (size_t)hp * 2 * CH;
-                            const Q16<T> ua = *reinterpret_cast<const Q16<T>*>(urow + swz_slot<NSU>(hp, oct) * VECN);
-                            const Q16<T> ug = *reinterpret_cast<const Q16<T>*>(urow + swz_slot<NSU>(hp, NOCT + oct) * VECN);
-#pragma unroll
-                            for (int o = 0; o < 2; ++o) {       // output row yr + o uses tap row dy = ry - o
-                                const int dy = ry - o;
-                                if (dy < 0 || dy > 2) continue;
-                                const int tap = dy * 3 + dx;
-                                if constexpr (BF) {
-                                    typedef bf16_t bf2 __attribute__((ext_vector_type(2)));
-                                    const bf2* wq = reinterpret_cast<const bf2*>(d.dww) + (((size_t)chunk * NOCT + oct) * 9 + tap) * 16;
-                                    const bf2* pa = reinterpret_cast<const bf2*>(&ua);
-                                    const bf2* pgp = reinterpret_cast<const bf2*>(&ug);
-#pragma unroll
-                                    for (int p = 0; p < 4; ++p) {
-                                        aA[o][2 * p] = __builtin_amdgcn_fdot2_f32_bf16(pa[p], wq[2 * p], aA[o][2 * p], false);
-                                        aA[o][2 * p + 1] = __builtin_amdgcn_fdot2_f32_bf16(pa[p], wq[2 * p + 1], aA[o][2 * p + 1], false);
-                                        aG[o][2 * p] = __builtin_amdgcn_fdot2_f32_bf16(pgp[p], wq[8 + 2 * p], aG[o][2 * p], false);
-                                        aG[o][2 * p + 1] = __builtin_amdgcn_fdot2_f32_bf16(pgp[p], wq[8 + 2 * p + 1], aG[o][2 * p + 1], false);
-                                    }
-                                } else {
-                                    const float* wq = reinterpret_cast<const float*>(d.dww) + (((size_t)chunk * NOCT + oct) * 9 + tap) * 8;
-#pragma unroll
-                                    for (int c = 0; c < VECN; ++c) {
-                                        aA[o][c] = fmaf(to_f(ua.v[c]), wq[c], aA[o][c]);
-                                        aG[o][c] = fmaf(to_f(ug.v[c]), wq[4 + c], aG[o][c]);
-                                    }
-                                }
-                            }
-                        }
-                    }
-#pragma unroll
-                    for (int o = 0; o < 2; ++o) {
-                        const int pix = (yr + o) * 16 + x;
-                        Q16<T> gv;
-#pragma unroll
-                        for (int c = 0; c < VECN; ++c) {
-                            const float gt = aG[o][c];
-                            const float sg = BF ? gt / (1.0f + __expf(-gt)) : gt / (1.0f + expf(-gt));
-                            gv.v[c] = to_T<T>(aA[o][c] * sg);
-                        }
-                        *reinterpret_cast<Q16<T>*>(Gs + (size_t)pix * CH + swz_slot<NSG>(pix, oct) * VECN) = gv;
-                    }
-                }
-            }
-        }
-        __syncthreads();
-
-        // ------------------------------------ fc2 ---------------------------------------------
-        {
-            typename M::frag_t bf[2];
-#pragma unroll
+        // ================================ phase C: gate + fc2 ===================================
+        if (chunk + 1 < d.chunks) load_a1(chunk + 1);  // next chunk's fc1 weights: in flight during gate + fc2
+#ifdef HAT_FFN_DEBUG_DUMP
+        {   // debug build only: dump chunk 0's U (64 channels of the pixel itself) and the depthwise accumulators
+            float* dbg = d.t_out + (size_t)b * H * W * C;
             for (int pt = 0; pt < 2; ++pt) {
-                const int pix = (2 * wave + pt) * 16 + c16;
-                const T* grow = Gs + (size_t)pix * CH;
-                if constexpr (BF) {
-                    bf[pt] = M::load(grow + swz_slot<NSG>(pix, g) * VECN);
-                } else {
-                    const f32x4 lo = *reinterpret_cast<const f32x4*>(grow + swz_slot<NSG>(pix, 2 * g) * VECN);
-                    const f32x4 hi = *reinterpret_cast<const f32x4*>(grow + swz_slot<NSG>(pix, 2 * g + 1) * VECN);
-                    bf[pt][0] = lo[0]; bf[pt][1] = lo[1]; bf[pt][2] = lo[2]; bf[pt][3] = lo[3];
-                    bf[pt][4] = hi[0]; bf[pt][5] = hi[1]; bf[pt][6] = hi[2]; bf[pt][7] = hi[3];
+                const int y = y0 + 2 * wave + pt, x = x0 + c16;
+                if (y < H && x < W) {
+                    const size_t pix = (size_t)y * W + x;
+                    const int hp = (2 * wave + pt + 1) * HALO_W + c16 + 1;
+                    for (int cc = 0; cc < 16; ++cc) {
+                        const int ch = 16 * g + cc;
+                        dbg[pix * C + ch] = to_f(Us[(size_t)hp * 2 * CH + swz_slot<NSU>(hp, ch / VECN) * VECN + (ch % VECN)]);
+                    }
+                    for (int gi = 0; gi < 4; ++gi)
+                        for (int r = 0; r < 4; ++r) dbg[pix * C + 64 + gi * 16 + 4 * g + r] = dacc[gi][pt][r];
                 }
             }
+            return;
+        }
+#endif
 #pragma unroll
-            for (int nt = 0; nt < NT; ++nt) {
-                const typename M::frag_t af = M::load(w2f + (((size_t)chunk * NT + nt) * 64 + lane) * 8);
-                acc2[nt][0] = M::mma(af, bf[0], acc2[nt][0]);
-                acc2[nt][1] = M::mma(af, bf[1], acc2[nt][1]);
+        for (int pt = 0; pt < 2; ++pt) {
+            // gate: G = a * SiLU(g); element (g, j<4) <- a-group 0 channel 4g+j, (g, j>=4) <- a-group 1 channel 4g+j-4
+            frag_t gf;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                float v0 = dacc[0][pt][r], v1 = dacc[1][pt][r];
+                if constexpr (!(DBG & 8)) {
+                    v0 *= BF ? silu_fast(dacc[2][pt][r]) : silu_exact(dacc[2][pt][r]);
+                    v1 *= BF ? silu_fast(dacc[3][pt][r]) : silu_exact(dacc[3][pt][r]);
+                }
+                gf[r] = to_T<T>(v0);
+                gf[4 + r] = to_T<T>(v1);
+            }
+            if constexpr (!(DBG & 16)) {
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt) acc2[nt][pt] = M::mma(a2[nt], gf, acc2[nt][pt]);
             }
         }
-        // no barrier needed here: the next fc1 writes Us (last read before the previous barrier) and the
-        // next dw stage writes Gs only after the barrier that follows that fc1
+        __syncthreads();  // every wave is done reading Us before the next chunk's fc1 overwrites it
     }
 
     // ----------------------------------- epilogue ------------------------------------------------
@@ -297,7 +368,7 @@ __global__ __launch_bounds__(WAVES * 64) void ffn_kernel(const HatFfnDesc d) {
             const int n = nt * 16 + 4 * g;
             f32x4 v = {0.f, 0.f, 0.f, 0.f};
             if (valid && n < C) {
-                v = acc2[nt][pt] + *reinterpret_cast<const f32x4*>(d.b2 + n) + *reinterpret_cast<const f32x4*>(tin + pix * C + n);
+                v = acc2[nt][pt] + *reinterpret_cast<const f32x4*>(tin + pix * C + n);
                 *reinterpret_cast<f32x4*>(tout + pix * C + n) = v;
             }
             acc2[nt][pt] = v;
@@ -333,8 +404,7 @@ __global__ __launch_bounds__(WAVES * 64) void ffn_kernel(const HatFfnDesc d) {
         }
     }
     if (do_ln && d.gap_out != nullptr) {
-        __syncthreads();  // Us is free: use it as the cross-wave reduction scratch
-        float* red = reinterpret_cast<float*>(Us);
+        float* red = reinterpret_cast<float*>(Us);  // Us is free after the last barrier of the chunk loop
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             float s = gapv[r];
@@ -352,11 +422,11 @@ __global__ __launch_bounds__(WAVES * 64) void ffn_kernel(const HatFfnDesc d) {
     }
 }
 
-template <typename T, int WAVES, int NT, int KS, bool KHALF>
+template <typename T, int WAVES, int NT, int KS, bool MSWZ>
 int launch_ffn(const HatFfnDesc& d, hipStream_t s) {
-    const size_t lds = ffn_lds_bytes<T, WAVES>(d.C);
+    const size_t lds = ffn_lds_bytes<T, WAVES, MSWZ>(d.C);
     if (lds > HAT_LDS_MAX) return HAT_ELDS;
-    auto kern = ffn_kernel<T, WAVES, NT, KS, KHALF>;
+    auto kern = ffn_kernel<T, WAVES, NT, KS, MSWZ>;
     if (lds > 65536) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return (int)e;
@@ -369,7 +439,7 @@ int launch_ffn(const HatFfnDesc& d, hipStream_t s) {
 // tile rows (= 2 * waves) used for (C, dtype); 0 if the shape is not instantiated
 int ffn_waves(const HatFfnDesc& d) {
     const bool small = d.C <= 32 && d.C % 32 != 16;  // one zero-padded 32-deep k-step
-    if (d.dtype == HAT_BF16) return d.C == 144 ? 8 : (d.C == 180 ? 4 : (small ? 8 : 0));
+    if (d.dtype == HAT_BF16) return (d.C == 144 || d.C == 180 || small) ? 4 : 0;
     if (d.dtype == HAT_F32) return (d.C == 144 || d.C == 180 || small) ? 2 : 0;
     return 0;
 }
@@ -394,11 +464,11 @@ extern "C" int hat_ffn(const HatFfnDesc* dp, void* stream) {
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     const bool small = d.C <= 32 && d.C % 32 != 16;
     if (d.dtype == HAT_BF16) {
-        if (d.C == 144) return launch_ffn<bf16_t, 8, 9, 5, true>(d, s);
+        if (d.C == 144) return launch_ffn<bf16_t, 4, 9, 5, true>(d, s);
         if (d.C == 180) return launch_ffn<bf16_t, 4, 12, 6, false>(d, s);
-        if (small) return launch_ffn<bf16_t, 8, 2, 1, false>(d, s);
+        if (small) return launch_ffn<bf16_t, 4, 2, 1, true>(d, s);
     } else if (d.dtype == HAT_F32) {
-        if (d.C == 144) return launch_ffn<float, 2, 9, 5, true>(d, s);
+        if (d.C == 144) return launch_ffn<float, 2, 9, 5, false>(d, s);
         if (d.C == 180) return launch_ffn<float, 2, 12, 6, false>(d, s);
         if (small) return launch_ffn<float, 2, 2, 1, false>(d, s);
     } else {

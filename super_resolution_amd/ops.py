@@ -51,14 +51,14 @@ class profile:
         return False
 
 
-def _timed(name, flops, fn):
+def _timed(name, flops, fn, tag=""):
     if _prof is None:
         return fn()
     s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     s.record()
     r = fn()
     e.record()
-    _prof.append((name, float(flops), s, e))
+    _prof.append((name, float(flops), s, e, tag))
     return r
 
 
@@ -150,7 +150,8 @@ def conv(pw: PackedConv, x: torch.Tensor, out: torch.Tensor, *, B: int, H: int, 
         # dynamic depthwise 3x3 that is folded into its weights (2*9*pdim per pixel).
         flops = 2.0 * B * H * W * (pw.ksize ** 2) * d.Cin * pw.nout + (2.0 * 9 * pw.nout * B * H * W if pw.w_bstride else 0.0)
     _timed(name, flops, lambda: _lib.check(lib.hat_conv(C.byref(d), _stream()),
-                                           f"hat_conv(k={pw.ksize}, Cin={d.Cin}, N={pw.nout})"))
+                                           f"hat_conv(k={pw.ksize}, Cin={d.Cin}, N={pw.nout})"),
+           tag=f"k{pw.ksize} {d.Cin}->{pw.nout} {H}x{W} x{x_mode} o{out_mode}{' r1' if r1 is not None else ''}{' r2' if r2 is not None else ''}")
 
 
 def conv_tiles(pw: PackedConv, H: int, W: int, dtype: int) -> int:
@@ -224,36 +225,34 @@ def pack_ffn(fc1_w, fc1_b, dw_w, dw_b, fc2_w, fc2_b, dtype: int, device) -> Pack
     assert W1.shape == (2 * hid, C_) and Wd.shape[0] == 2 * hid
     chunks = -(-hid // 32)
     hid_p = 32 * chunks
-    khalf = C_ % 32 == 16
-    ks = C_ // 32 + 1 if khalf else -(-C_ // 32)
+    khalf = False
+    ks = -(-(C_ + 1) // 32)          # K padded to a multiple of 32 with room for the bias column at k = C
     nt = 9 if C_ == 144 else (12 if C_ == 180 else 2)
     tdt = TORCH_DTYPE[dtype]
     lane = torch.arange(64)
     n16, g4 = lane & 15, lane >> 4
     j8 = torch.arange(8)
-    # ---- fc1: w1f[chunk][nt4][ks][lane][8]
-    W1p = torch.zeros(2 * hid_p + 1, ks * 32 + 32)  # padded copy; last row = zeros for invalid rows
+    # ---- fc1: w1f[chunk][nt4][ks][lane][8]; column C of the padded weight matrix is the fc1 bias (the kernel
+    # keeps a constant 1 in column C of the LayerNorm'ed activations)
+    W1p = torch.zeros(2 * hid_p, ks * 32)
     W1p[:hid, :C_] = W1[:hid]
     W1p[hid_p:hid_p + hid, :C_] = W1[hid:]
+    W1p[:hid, C_] = b1[:hid]
+    W1p[hid_p:hid_p + hid, C_] = b1[hid:]
     c_i = torch.arange(chunks)[:, None, None, None, None]
     nt_i = torch.arange(4)[None, :, None, None, None]
     ks_i = torch.arange(ks)[None, None, :, None, None]
     nl = nt_i * 16 + n16[None, None, None, :, None]                       # chunk-local channel 0..63
-    row = torch.where(nl < 32, c_i * 32 + nl, hid_p + c_i * 32 + (nl - 32))
-    kfull = ks_i * 32 + 8 * g4[None, None, None, :, None] + j8[None, None, None, None, :]
-    col = kfull.expand(chunks, 4, ks, 64, 8).clone()
-    row = row.expand(chunks, 4, ks, 64, 8)
+    row = torch.where(nl < 32, c_i * 32 + nl, hid_p + c_i * 32 + (nl - 32)).expand(chunks, 4, ks, 64, 8)
+    col = (ks_i * 32 + 8 * g4[None, None, None, :, None] + j8[None, None, None, None, :]).expand(chunks, 4, ks, 64, 8)
     w1f = W1p[row, col]
-    if khalf:  # last k-step is 16 deep: element j<4 <-> k = 32*(ks-1) + 4*g + j, elements 4..7 unused
-        khcol = (ks - 1) * 32 + 4 * g4[:, None] + j8[None, :4]             # (64, 4)
-        last = W1p[row[:, :, ks - 1, :, :4], khcol[None, None].expand(chunks, 4, 64, 4)]
-        w1f[:, :, ks - 1] = 0
-        w1f[:, :, ks - 1, :, :4] = last
-    # ---- fc2: w2f[chunk][nt][lane][8]
+    # ---- fc2: w2f[chunk][nt][lane][8]; the k order inside the 32-deep chunk is the accumulator order of the
+    # depthwise stage: element (g, j<4) <-> channel 4g+j of a-group 0, (g, j>=4) <-> channel 16+4g+(j-4)
     W2p = torch.zeros(nt * 16, hid_p)
     W2p[:C_, :hid] = W2
     n_i = (torch.arange(nt)[:, None] * 16 + n16[None, :])                  # (nt, 64)
-    k_i = torch.arange(chunks)[:, None, None] * 32 + 8 * g4[None, :, None] + j8[None, None, :]  # (chunks, 64, 8)
+    kloc = torch.where(j8[None, :] < 4, 4 * g4[:, None] + j8[None, :], 16 + 4 * g4[:, None] + (j8[None, :] - 4))  # (64, 8)
+    k_i = torch.arange(chunks)[:, None, None] * 32 + kloc[None]            # (chunks, 64, 8)
     w2f = W2p[n_i[None, :, :, None].expand(chunks, nt, 64, 8), k_i[:, None].expand(chunks, nt, 64, 8)]
     # ---- biases
     b1p = torch.zeros(2 * hid_p)
@@ -262,17 +261,24 @@ def pack_ffn(fc1_w, fc1_b, dw_w, dw_b, fc2_w, fc2_b, dtype: int, device) -> Pack
     dwb[:hid], dwb[hid_p:hid_p + hid] = bd[:hid], bd[hid:]
     b2p = torch.zeros(nt * 16)
     b2p[:C_] = b2
-    # ---- depthwise weights
-    Wdp = torch.zeros(2, hid_p, 9)
-    Wdp[0, :hid], Wdp[1, :hid] = Wd[:hid], Wd[hid:]
-    if dtype == HAT_BF16:  # [chunk][octet 4][tap 9][half 2][8 pairs]: pair 2p = (w[c0+2p], 0), pair 2p+1 = (0, w[c0+2p+1])
-        wd = Wdp.reshape(2, chunks, 4, 8, 9).permute(1, 2, 4, 0, 3)          # (chunks, 4, 9, 2, 8 channels)
-        dww = torch.zeros(chunks, 4, 9, 2, 8, 2)
-        dww[..., 0::2, 0] = wd[..., 0::2]
-        dww[..., 1::2, 1] = wd[..., 1::2]
-        dww = dww.to(torch.bfloat16)
-    else:                   # [chunk][quad 8][tap 9][half 2][4]
-        dww = Wdp.reshape(2, chunks, 8, 4, 9).permute(1, 2, 4, 0, 3).contiguous()
+    # ---- depthwise weights, one value per (chunk, lane, group of 16 channels, tap pair): lane (n = l&15, g = l>>4)
+    # owns channel n of the group and tap 2*pair + (g>>1) (tap 9 = the depthwise BIAS, multiplied by a constant 1 in
+    # the kernel); non-zero only in the lanes whose 8-wide k group holds channel n (n>>3 == g&1), so the kernel
+    # builds its diagonal A fragment from this single value.  bf16: stored duplicated in both halves of a dword.
+    Wd_a, Wd_g = torch.zeros(hid_p, 10), torch.zeros(hid_p, 10)
+    Wd_a[:hid, :9], Wd_g[:hid, :9] = Wd[:hid], Wd[hid:]
+    Wd_a[:hid, 9], Wd_g[:hid, 9] = bd[:hid], bd[hid:]
+    Wdp = torch.stack([Wd_a.reshape(chunks, 2, 16, 10)[:, 0], Wd_a.reshape(chunks, 2, 16, 10)[:, 1],
+                       Wd_g.reshape(chunks, 2, 16, 10)[:, 0], Wd_g.reshape(chunks, 2, 16, 10)[:, 1]])  # [group][chunk][ch][tap]
+    tap = 2 * torch.arange(5)[None, :] + (g4[:, None] >> 1)                  # (64, 5)
+    active = ((n16 >> 3) == (g4 & 1)).to(torch.float32)                      # (64,)
+    dww = torch.zeros(chunks, 64, 4, 5)
+    for gi in range(4):
+        dww[:, :, gi, :] = Wdp[gi][:, n16[:, None].expand(64, 5), tap] * active[None, :, None]
+    dww = dww.reshape(chunks, 64, 20)
+    if dtype == HAT_BF16:
+        bits = dww.to(torch.bfloat16).view(torch.int16).to(torch.int32) & 0xFFFF
+        dww = (bits | (bits << 16)).to(torch.int32)
     p = PackedFFN()
     p.w1f, p.w2f = w1f.to(tdt).contiguous().to(device), w2f.to(tdt).contiguous().to(device)
     p.b1, p.dwb, p.b2 = b1p.to(device), dwb.to(device), b2p.to(device)

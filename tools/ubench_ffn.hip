@@ -1,0 +1,64 @@
+// tools/ubench_ffn.hip — timing ablation of the fused FFN kernel (NOT part of the library or the tests).
+//   hipcc -O3 --offload-arch=gfx950 -std=c++17 tools/ubench_ffn.hip -o tools/bin/ubench_ffn && tools/bin/ubench_ffn
+#include "../super_resolution_amd/csrc/hat_ffn.hip"
+#include <cstdio>
+#include <cstdlib>
+#include <vector>
+
+#define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("HIP error %d at %s:%d\n", (int)e_, __FILE__, __LINE__); return 1; } } while (0)
+
+__global__ void fill(float* p, size_t n, float s) { size_t i = blockIdx.x * (size_t)256 + threadIdx.x; if (i < n) p[i] = s * (float)((i * 2654435761u) % 1000) / 1000.f - 0.5f * s; }
+__global__ void fillh(bf16_t* p, size_t n, float s) { size_t i = blockIdx.x * (size_t)256 + threadIdx.x; if (i < n) p[i] = (bf16_t)(s * (float)((i * 2654435761u) % 1000) / 1000.f - 0.5f * s); }
+
+template <int WV, int DBG> float run(const HatFfnDesc& d, int iters) {
+    auto kern = ffn_kernel<bf16_t, WV, 9, 5, true, DBG>;
+    const size_t lds = ffn_lds_bytes<bf16_t, WV, true>(d.C);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    dim3 grid((d.W + 15) / 16, (d.H + 2 * WV - 1) / (2 * WV), d.B);
+    hipEvent_t a, b; (void)hipEventCreate(&a); (void)hipEventCreate(&b);
+    for (int i = 0; i < 2; ++i) hipLaunchKernelGGL(kern, grid, dim3(WV * 64), lds, 0, d);
+    (void)hipEventRecord(a, 0);
+    for (int i = 0; i < iters; ++i) hipLaunchKernelGGL(kern, grid, dim3(WV * 64), lds, 0, d);
+    (void)hipEventRecord(b, 0); (void)hipEventSynchronize(b);
+    float ms = 0; (void)hipEventElapsedTime(&ms, a, b);
+    return ms / iters;
+}
+
+int main() {
+    const int H = 720, W = 1280, C = 144, chunks = 9;
+    const size_t N = (size_t)H * W;
+    float *tin, *tout, *vec; bf16_t *w1f, *w2f, *dww, *nout;
+    CK(hipMalloc(&tin, N * C * 4)); CK(hipMalloc(&tout, N * C * 4)); CK(hipMalloc(&vec, 8192 * 4));
+    CK(hipMalloc(&w1f, (size_t)chunks * 4 * 5 * 64 * 8 * 2)); CK(hipMalloc(&w2f, (size_t)chunks * 9 * 64 * 8 * 2));
+    CK(hipMalloc(&dww, (size_t)chunks * 64 * 20 * 4)); CK(hipMalloc(&nout, N * C * 2));
+    fill<<<(N * C + 255) / 256, 256>>>(tin, N * C, 2.f);
+    fill<<<32, 256>>>(vec, 8192, 0.2f);
+    fillh<<<(chunks * 4 * 5 * 64 * 8 + 255) / 256, 256>>>(w1f, (size_t)chunks * 4 * 5 * 64 * 8, 0.15f);
+    fillh<<<(chunks * 9 * 64 * 8 + 255) / 256, 256>>>(w2f, (size_t)chunks * 9 * 64 * 8, 0.1f);
+    fillh<<<(chunks * 64 * 20 * 2 + 255) / 256, 256>>>(dww, (size_t)chunks * 64 * 20 * 2, 0.3f);
+    CK(hipDeviceSynchronize());
+    HatFfnDesc d = {};
+    d.t_in = tin; d.t_out = tout; d.ln_g = vec; d.ln_b = vec + 256; d.w1f = w1f; d.b1 = vec + 512; d.dww = dww; d.dwb = vec + 2048;
+    d.w2f = w2f; d.b2 = vec + 4096; d.B = 1; d.H = H; d.W = W; d.C = C; d.chunks = chunks; d.dtype = HAT_BF16;
+    const int it = 5;
+    if (getenv("UB_ONLY_FULL")) { printf("full %.3f ms\n", run<4, 0>(d, 3)); return 0; }
+#define ROW(WV, M, label) printf("%-34s %.3f ms\n", label, run<WV, M>(d, it))
+    printf("---- 4 waves (8x16 tile, 2 WG/CU)\n");
+    ROW(4, 0, "full");
+    ROW(4, 1, "no LN stage");
+    ROW(4, 2, "no fc1 mfma");
+    ROW(4, 4, "no dw mfma");
+    ROW(4, 8, "no gate math");
+    ROW(4, 16, "no fc2 mfma");
+    ROW(4, 32, "no weight loads");
+    ROW(4, 2 | 4 | 16, "no mfma at all");
+    ROW(4, 2 | 4 | 8 | 16 | 32, "LN + skeleton + epilogue");
+    ROW(4, 1 | 2 | 4 | 8 | 16 | 32, "skeleton + epilogue");
+    printf("---- 8 waves (16x16 tile, 1 WG/CU)\n");
+    ROW(8, 0, "full");
+    ROW(8, 1, "no LN stage");
+    ROW(8, 2 | 4 | 16, "no mfma at all");
+    d.ln1_g = vec + 5000; d.ln1_b = vec + 5300; d.n_out = nout; d.ldn = C;
+    ROW(4, 0, "4 waves full + fused next LN");
+    return 0;
+}
