@@ -31,11 +31,19 @@ __host__ inline bool conv_pick(const HatConvDesc& d, TileCfg* out, size_t* lds) 
     const int es = d.dtype == HAT_BF16 ? 2 : 4;
     const int kc = d.dtype == HAT_BF16 ? 64 : 32;
     const TileCfg cands[3] = {{8, 2}, {4, 2}, {4, 1}};
-    for (int i = 0; i < 3; ++i) {
-        const int rows = cands[i].waves * cands[i].pt;
-        if (i < 2 && d.H * 2 <= rows) continue;  // do not waste most of a tall tile on a short image
-        const size_t b = conv_lds_bytes(d, cands[i].waves, cands[i].pt, es, kc);
-        if (b <= HAT_LDS_MAX) { *out = cands[i]; *lds = b; return true; }
+    // first choice: the largest tile that still lets TWO workgroups share a CU (LDS <= 80 KiB each), so one
+    // workgroup's load / store phases overlap the other's MFMA phase — only when the weight slice is cheap to
+    // re-stream per tile (smaller tiles re-read it more often); otherwise the largest tile that fits
+    const size_t wbytes = (size_t)d.nt * 16 * d.ksize * d.ksize * ((d.Cin + 7) & ~7) * es;
+    for (int pass = (wbytes <= 65536 ? 0 : 1); pass < 2; ++pass) {
+        const size_t limit = pass == 0 ? HAT_LDS_MAX / 2 : HAT_LDS_MAX;
+        for (int i = 0; i < 3; ++i) {
+            const int rows = cands[i].waves * cands[i].pt;
+            if (i < 2 && d.H * 2 <= rows) continue;  // do not waste most of a tall tile on a short image
+            if (pass == 0 && i == 2) continue;       // a 1-row-per-wave tile is not worth it just for occupancy
+            const size_t b = conv_lds_bytes(d, cands[i].waves, cands[i].pt, es, kc);
+            if (b <= limit) { *out = cands[i]; *lds = b; return true; }
+        }
     }
     return false;
 }

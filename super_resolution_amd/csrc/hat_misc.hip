@@ -104,32 +104,40 @@ int launch_ln(const float* x, void* y, const float* gamma, const float* beta, fl
 // ESC per-sample weights: one block per (output channel co, sample b).
 // ---------------------------------------------------------------------------------------------
 template <typename T>
-__global__ __launch_bounds__(256) void esc_weights_kernel(const float* __restrict__ gap_partial, int nblk, float inv_npix,
+__global__ __launch_bounds__(1024) void esc_weights_kernel(const float* __restrict__ gap_partial, int nblk, float inv_npix,
                                                           const float* __restrict__ w1, const float* __restrict__ b1,
                                                           const float* __restrict__ w2, const float* __restrict__ b2,
                                                           const float* __restrict__ plk, T* __restrict__ w_out,
                                                           int pdim, int ksize, int Kpad) {
-    __shared__ float part[16][16];
+    __shared__ float part[64][16];
     __shared__ float pmean[16];
     __shared__ float hid[8];
     __shared__ float dk[9];
     const int tid = threadIdx.x, co = blockIdx.x, b = blockIdx.y;
     if (co >= pdim) {  // rows pdim..15 of the 16-row MFMA tile are zero
         T* z = w_out + ((size_t)b * 16 + co) * Kpad;
-        for (int k = tid; k < Kpad; k += 256) z[k] = to_T<T>(0.f);
+        for (int k = tid; k < Kpad; k += 1024) z[k] = to_T<T>(0.f);
         return;
     }
-    {
+    {   // fixed-order two-level reduction of the GAP partials: 64 strided parts, 4 independent chains each
         const int ci = tid & 15, pp = tid >> 4;
-        float s = 0.f;
-        for (int k = pp; k < nblk; k += 16) s += gap_partial[((size_t)b * nblk + k) * 16 + ci];
-        part[pp][ci] = s;
+        float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+        const float* gp = gap_partial + (size_t)b * nblk * 16 + ci;
+        int k = pp;
+        for (; k + 192 < nblk; k += 256) {
+            s0 += gp[(size_t)k * 16];
+            s1 += gp[(size_t)(k + 64) * 16];
+            s2 += gp[(size_t)(k + 128) * 16];
+            s3 += gp[(size_t)(k + 192) * 16];
+        }
+        for (; k < nblk; k += 64) s0 += gp[(size_t)k * 16];
+        part[pp][ci] = (s0 + s1) + (s2 + s3);
     }
     __syncthreads();
     if (tid < 16) {
         float s = 0.f;
 #pragma unroll
-        for (int k = 0; k < 16; ++k) s += part[k][tid];
+        for (int k = 0; k < 64; ++k) s += part[k][tid];
         pmean[tid] = s * inv_npix;
     }
     __syncthreads();
@@ -151,7 +159,7 @@ __global__ __launch_bounds__(256) void esc_weights_kernel(const float* __restric
     const int ctr = ksize / 2;
     const float* src = plk + (size_t)co * Kpad;
     T* dst = w_out + ((size_t)b * 16 + co) * Kpad;
-    for (int k = tid; k < Kpad; k += 256) {
+    for (int k = tid; k < Kpad; k += 1024) {
         float v = src[k];
         const int tap = k / cin_p, ci = k - tap * cin_p;
         if (ci == co && tap < ksize * ksize) {
@@ -263,7 +271,7 @@ extern "C" int hat_esc_weights(const float* gap_partial, int32_t nblk, int64_t n
     if (!gap_partial || !w1 || !b1 || !w2 || !b2 || !plk_packed || !w_out) return HAT_EINVAL;
     if (pdim < 2 || pdim > 16 || pdim % 4 || ksize < 3 || (ksize & 1) == 0 || B < 1 || nblk < 1) return HAT_EINVAL;
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
-    dim3 grid(16, B), block(256);
+    dim3 grid(16, B), block(1024);
     const float inv = 1.0f / (float)npix;
     if (dtype == HAT_BF16)
         HAT_LAUNCH(esc_weights_kernel<bf16_t>, grid, block, 0, s, gap_partial, nblk, inv, w1, b1, w2, b2, plk_packed,
