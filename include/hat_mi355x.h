@@ -87,6 +87,16 @@ int hat_conv_plan(const HatConvDesc* d, int32_t* waves, int32_t* rows_per_wave, 
 int hat_conv(const HatConvDesc* d, void* stream);
 
 /*
+ * Pointwise linear layer (ksize == 1, channel-last T input, HAT_O_NHWC_T / HAT_O_NHWC_F32 output, same epilogue
+ * as hat_conv without column sums) as a weight-stationary, barrier-free streaming GEMM: the layers it serves
+ * (hat_arch.py:309-313,347,350,391; esc_arch.py:144) are HBM-bound.  Same descriptor as hat_conv, but `w` is
+ * FRAGMENT packed: [n_slices][nt][ceil(Cin/32)][64 lanes][8] with element (lane l, j) =
+ * W[slice*nt*16 + t*16 + (l & 15)][32*ks + 8*(l >> 4) + j] (zero beyond Cin / n); Kpad is ignored.
+ * Returns HAT_EUNSUPPORTED for (nt, Cin) pairs that are not instantiated: call hat_conv instead.
+ */
+int hat_linear(const HatConvDesc* d, void* stream);
+
+/*
  * LayerNorm over the channel dimension (eps 1e-5, affine), fp32 in -> T or fp32 out
  * (nn.LayerNorm at hat_arch.py:209,214,291,306,743 and PatchEmbed.norm :573-574).
  * Optionally emits per-block partial sums of the first `gap_c` output channels

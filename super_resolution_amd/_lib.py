@@ -62,6 +62,7 @@ SIGNATURES = {
     "hat_conv_plan": (C.c_int, [C.POINTER(HatConvDesc), C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.POINTER(C.c_int32),
                                 C.POINTER(C.c_int64)]),
     "hat_conv": (C.c_int, [C.POINTER(HatConvDesc), C.c_void_p]),
+    "hat_linear": (C.c_int, [C.POINTER(HatConvDesc), C.c_void_p]),
     "hat_ffn_tiles": (C.c_int, [C.POINTER(HatFfnDesc), C.POINTER(C.c_int32)]),
     "hat_ffn": (C.c_int, [C.POINTER(HatFfnDesc), C.c_void_p]),
     "hat_layernorm_blocks": (C.c_int, []),

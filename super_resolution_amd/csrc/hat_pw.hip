@@ -1,0 +1,174 @@
+// hat_pw.hip — pointwise linear layers (nn.Linear / 1x1 conv on channel-last tokens) as a weight-stationary,
+// barrier-free streaming GEMM on gfx950.  Contract: hat_linear in include/hat_mi355x.h (it takes the same
+// HatConvDesc as hat_conv with ksize == 1, but the weights are FRAGMENT packed).
+//
+// These layers (ESC aggr, OCAB q/kv/proj/MLP; hat_arch.py:309-313,347,350,391, esc_arch.py:144) have K, N <= 360
+// and 1e6 pixels: they are HBM-bound (70-115 FLOP/B vs a ridge of ~400), so the structure is chosen for bytes in
+// flight, not MFMA rate:
+//   * one n-slice of the weight matrix (<= 192 x K) lives in LDS for the whole life of the workgroup, already in
+//     MFMA A-fragment order (a fragment is 1 KiB read as base + lane*16: conflict free);
+//   * every wave walks its own 16-pixel tiles (flat pixel order, persistent grid): B fragments come straight
+//     from global memory into registers (one tile ahead), no LDS staging of activations, NO barrier in the loop,
+//     so waves free-run and 12-16 of them per CU keep HBM requests in flight;
+//   * the epilogue (bias, GELU, fp32 residual, scaled T residual) is applied on the accumulators: a lane owns
+//     4 consecutive channels of one pixel.
+#include "hat_common.h"
+
+namespace {
+
+template <typename T, int NT, int KS, int WAVES, int MINW>
+__global__ __launch_bounds__(WAVES * 64, MINW) void pw_kernel(const HatConvDesc d, long npix_total, int tiles) {
+    using M = MT<T>;
+    using frag_t = typename M::frag_t;
+    constexpr int KSMAX = KS;
+    constexpr int ks_total = KS;
+    constexpr int nthr = WAVES * 64, nwaves = WAVES;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    T* Wl = reinterpret_cast<T*>(smem);  // [NT][ks][64 lanes][8]
+    const int tid = threadIdx.x, lane = tid & 63, g = lane >> 4, c16 = lane & 15;
+    const int wave = tid >> 6;
+    const int slice = blockIdx.y;
+    const int nbase = slice * NT * 16;
+    const T* wg = reinterpret_cast<const T*>(d.w) + (size_t)slice * NT * ks_total * 512;  // 512 elements per fragment
+    for (int i = tid; i < NT * ks_total * 64 * (int)sizeof(T) / 2; i += nthr)  // 16 bytes per item
+        *reinterpret_cast<u32x4*>(smem + (size_t)i * 16) = *reinterpret_cast<const u32x4*>(reinterpret_cast<const char*>(wg) + (size_t)i * 16);
+    f32x4 bias[NT];
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) bias[nt] = *reinterpret_cast<const f32x4*>(d.bias + nbase + nt * 16 + 4 * g);
+    __syncthreads();
+
+    const T* xg = reinterpret_cast<const T*>(d.x);
+    const T* xg0 = reinterpret_cast<const T*>(d.x0);
+    const int Cin = d.Cin;
+    auto load_b = [&](long tile, frag_t (&bf)[KSMAX]) {
+        long p = tile * 16 + c16;
+        p = p < npix_total ? p : npix_total - 1;
+#pragma unroll
+        for (int ks = 0; ks < KSMAX; ++ks) {
+            if (ks < ks_total) {
+                const int c = ks * 32 + 8 * g;
+                if (c + 8 <= Cin || (sizeof(T) == 2 && c < Cin)) {  // bf16 rows are padded to a multiple of 8 channels
+                    const T* src = (xg0 != nullptr && c < d.c_split) ? xg0 + p * d.ldx0 + c : xg + p * d.ldx + c;
+                    bf[ks] = M::load(src);
+                } else if (c < Cin) {                                // f32 tail: 4 valid channels
+                    const f32x4 lo = *reinterpret_cast<const f32x4*>(xg + p * d.ldx + c);
+                    frag_t t = M::zero();
+                    t[0] = to_T<T>(lo[0]); t[1] = to_T<T>(lo[1]); t[2] = to_T<T>(lo[2]); t[3] = to_T<T>(lo[3]);
+                    bf[ks] = t;
+                } else {
+                    bf[ks] = M::zero();
+                }
+            }
+        }
+    };
+
+    const long stride = (long)gridDim.x * nwaves;
+    long tile = (long)blockIdx.x * nwaves + wave;
+    frag_t bcur[KSMAX], bnxt[KSMAX];
+    if (tile < tiles) load_b(tile, bcur);
+    for (; tile < tiles; tile += stride) {
+        if (tile + stride < tiles) load_b(tile + stride, bnxt);
+        f32x4 acc[NT];
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) acc[nt] = f32x4{0.f, 0.f, 0.f, 0.f};
+        // The weight fragments are re-read from LDS for every tile: make the address opaque per iteration, or the
+        // compiler hoists all NT*KS loop-invariant fragments into registers and spills.
+        int wofs = lane * 8;
+        asm volatile("" : "+v"(wofs));
+#pragma unroll
+        for (int ks = 0; ks < KSMAX; ++ks) {
+            if (ks < ks_total) {
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt) {
+                    const frag_t af = M::load(Wl + (size_t)(nt * ks_total + ks) * 512 + wofs);
+                    acc[nt] = M::mma(af, bcur[ks], acc[nt]);
+                }
+            }
+        }
+        const long p = tile * 16 + c16;
+        if (p < npix_total) {
+            const long bidx = p / ((long)d.H * d.W);
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) {
+                const int n = nbase + nt * 16 + 4 * g;
+                if (n < d.n_store) {
+                    f32x4 v = acc[nt] + bias[nt];
+                    if (d.act == HAT_ACT_GELU) {
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) v[r] = gelu_erf(v[r]);
+                    } else if (d.act == HAT_ACT_LRELU) {
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) v[r] = v[r] >= 0.f ? v[r] : 0.01f * v[r];
+                    }
+                    if (d.r1 != nullptr) v += *reinterpret_cast<const f32x4*>(d.r1 + p * d.ldr1 + n);
+                    if (d.r2 != nullptr) {
+                        const f32x4 rv = Vec4<T>::load(reinterpret_cast<const T*>(d.r2) + p * d.ldr2 + n);
+                        v += *reinterpret_cast<const f32x4*>(d.r2scale + bidx * d.r2scale_bstride + n) * rv;
+                    }
+                    if (d.out_mode == HAT_O_NHWC_T) Vec4<T>::store(reinterpret_cast<T*>(d.out) + p * d.ldo + n, v);
+                    else *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(d.out) + p * d.ldo + n) = v;
+                }
+            }
+        }
+#pragma unroll
+        for (int ks = 0; ks < KSMAX; ++ks) bcur[ks] = bnxt[ks];
+    }
+}
+
+template <typename T, int NT, int KS>
+int launch_pw(const HatConvDesc& d, hipStream_t s) {
+    const size_t lds = (size_t)NT * KS * 64 * 8 * sizeof(T);  // a fragment is 64 lanes x 8 elements
+    if (lds > HAT_LDS_MAX) return HAT_EUNSUPPORTED;
+    const long npix = (long)d.B * d.H * d.W;
+    const int tiles = (int)((npix + 15) / 16);
+    int wgs_per_cu = (int)(HAT_LDS_MAX / lds);
+    wgs_per_cu = wgs_per_cu > 3 ? 3 : wgs_per_cu;
+    const bool big = wgs_per_cu < 2;  // one big-LDS workgroup per CU gets 8 waves, otherwise 4 waves x up to 3 workgroups
+    const int waves = big ? 8 : 4;
+    int gx = 256 * wgs_per_cu;
+    if (gx > (tiles + waves - 1) / waves) gx = (tiles + waves - 1) / waves;
+    dim3 grid(gx, d.n_slices, 1);
+    // waves per SIMD the register allocation is sized for: 3 workgroups x 4 waves -> 3, 2 x 4 -> 2, 1 x 8 -> 2
+    if (big) {
+        auto kern = pw_kernel<T, NT, KS, 8, 2>;
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return (int)e;
+        HAT_LAUNCH(kern, grid, dim3(512), lds, s, d, npix, tiles);
+    } else if (wgs_per_cu == 2) {
+        auto kern = pw_kernel<T, NT, KS, 4, 2>;
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return (int)e;
+        HAT_LAUNCH(kern, grid, dim3(256), lds, s, d, npix, tiles);
+    } else {
+        auto kern = pw_kernel<T, NT, KS, 4, 3>;
+        HAT_LAUNCH(kern, grid, dim3(256), lds, s, d, npix, tiles);
+    }
+    return hat_check_launch();
+}
+
+}  // namespace
+
+extern "C" int hat_linear(const HatConvDesc* dp, void* stream) {
+    if (!dp) return HAT_EINVAL;
+    const HatConvDesc& d = *dp;
+    if (!d.x || !d.w || !d.bias || !d.out || d.ksize != 1 || d.B < 1 || d.H < 1 || d.W < 1 || d.Cin < 4) return HAT_EINVAL;
+    if (d.x_mode != HAT_X_NHWC_T || (d.out_mode != HAT_O_NHWC_T && d.out_mode != HAT_O_NHWC_F32)) return HAT_EINVAL;
+    if (d.n_store % 4 || d.ldo % 4 || d.n_store > d.n_slices * d.nt * 16 || d.colsum) return HAT_EINVAL;
+    const int vec = d.dtype == HAT_BF16 ? 8 : 4;
+    if (d.ldx % vec || d.Cin % 4 || (d.x0 && (d.ldx0 % vec || d.c_split % vec || d.c_split > d.Cin))) return HAT_EINVAL;
+    if ((d.r1 && d.ldr1 % 4) || (d.r2 && (d.ldr2 % 4 || !d.r2scale))) return HAT_EINVAL;
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    const int ks = (d.Cin + 31) / 32;
+#define HAT_PW_CASE(TT)                                                   \
+    if (d.nt == 9 && ks == 5) return launch_pw<TT, 9, 5>(d, s);           \
+    if (d.nt == 9 && ks == 9) return launch_pw<TT, 9, 9>(d, s);           \
+    if (d.nt == 12 && ks == 6) return launch_pw<TT, 12, 6>(d, s);         \
+    if (d.nt == 12 && ks == 12) return launch_pw<TT, 12, 12>(d, s);       \
+    if (d.nt == 4 && ks == 1) return launch_pw<TT, 4, 1>(d, s);           \
+    if (d.nt == 4 && ks == 2) return launch_pw<TT, 4, 2>(d, s);
+    if (d.dtype == HAT_BF16) { HAT_PW_CASE(bf16_t) }
+    else if (d.dtype == HAT_F32) { HAT_PW_CASE(float) }
+    else return HAT_EINVAL;
+#undef HAT_PW_CASE
+    return HAT_EUNSUPPORTED;  // shapes not instantiated here: use hat_conv (ksize 1)
+}

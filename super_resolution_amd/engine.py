@@ -54,7 +54,8 @@ class _ESC:
         plk[:, :min(self.kpad, lk.kpad)] = lk.w[:16, :min(self.kpad, lk.kpad)]
         self.plk = plk.contiguous()
         self.zero_bias = torch.zeros(16, **f32)
-        self.aggr = ops.pack_conv_weight(sd[core + ".aggr.weight"], sd[core + ".aggr.bias"], dtype, dev)
+        self.aggr = None  # packed by the engine (hat_linear when the shape is instantiated)
+        self.aggr_keys = (core + ".aggr.weight", core + ".aggr.bias")
 
 
 class HATEngine:
@@ -84,6 +85,22 @@ class HATEngine:
         self._pack(state_dict)
 
     # ------------------------------------------------------------------------------------------
+    def _lin(self, sd, wkey, bkey, scale=1.0):
+        """Pack a pointwise layer for hat_linear when its shape is instantiated, else for hat_conv (ksize 1)."""
+        w = sd[wkey]
+        b = sd.get(bkey) if bkey else None
+        o, i = w.shape[0], w.reshape(w.shape[0], -1).shape[1]
+        if ops.linear_supported(o, i, self.dtype):
+            pw = ops.pack_linear_weight(w, b, self.dtype, self.dev, scale=scale)
+            pw.frag = True
+            return pw
+        pw = ops.pack_conv_weight(w, b, self.dtype, self.dev, scale=scale)
+        pw.frag = False
+        return pw
+
+    def _run_lin(self, pw, x, out, **kw):
+        (ops.linear if pw.frag else ops.conv)(pw, x, out, **kw)
+
     def _pack(self, sd):
         cfg, dt, dev, C = self.cfg, self.dtype, self.dev, self.C
         f32 = dict(dtype=torch.float32, device=dev)
@@ -107,9 +124,11 @@ class HATEngine:
                     "cab0": P(p + ".conv_block.cab.0.weight", p + ".conv_block.cab.0.bias"),
                     "cab2": P(p + ".conv_block.cab.2.weight", p + ".conv_block.cab.2.bias"),
                     "eca_w": vec(p + ".conv_block.cab.3.conv.weight").reshape(-1),
-                    "fc1": P(p + ".mlp.fc1.weight", p + ".mlp.fc1.bias"),
-                    "fc2": P(p + ".mlp.fc2.weight", p + ".mlp.fc2.bias"),
                 }
+                hb["esc"].aggr = self._lin(sd, *hb["esc"].aggr_keys)
+                if not self.fuse_ffn:
+                    hb["fc1"] = self._lin(sd, p + ".mlp.fc1.weight", p + ".mlp.fc1.bias")
+                    hb["fc2"] = self._lin(sd, p + ".mlp.fc2.weight", p + ".mlp.fc2.bias")
                 hid2 = sd[p + ".mlp.dw.weight"].shape[0]
                 hb["dw_w"] = sd[p + ".mlp.dw.weight"].detach().to(**f32).reshape(hid2, 9).t().contiguous()  # [9][2*hid]
                 hb["dw_b"] = vec(p + ".mlp.dw.bias")
@@ -125,15 +144,16 @@ class HATEngine:
                 "n1": (vec(p + ".norm1.weight"), vec(p + ".norm1.bias")),
                 "n2": (vec(p + ".norm2.weight"), vec(p + ".norm2.bias")),
                 # q * scale (hat_arch.py:375) is folded into the projection
-                "q": ops.pack_conv_weight(sd[p + ".q_proj.weight"], sd.get(p + ".q_proj.bias"), dt, dev, scale=qscale),
-                "kv": ops.pack_conv_weight(sd[p + ".kv_proj.weight"], sd.get(p + ".kv_proj.bias"), dt, dev),
-                "proj": P(p + ".proj.weight", p + ".proj.bias"),
-                "mlp0": P(p + ".mlp.0.weight", p + ".mlp.0.bias"),
-                "mlp2": P(p + ".mlp.2.weight", p + ".mlp.2.bias"),
+                "q": self._lin(sd, p + ".q_proj.weight", p + ".q_proj.bias", scale=qscale),
+                "kv": self._lin(sd, p + ".kv_proj.weight", p + ".kv_proj.bias"),
+                "proj": self._lin(sd, p + ".proj.weight", p + ".proj.bias"),
+                "mlp0": self._lin(sd, p + ".mlp.0.weight", p + ".mlp.0.bias"),
+                "mlp2": self._lin(sd, p + ".mlp.2.weight", p + ".mlp.2.bias"),
                 "bias_rot": table[rot].t().contiguous().to(dev),  # [heads][M*M]
             }
             if cfg.get("ocab_esc_enable", False):
                 oc["esc"] = _ESC(sd, p + ".esc_core", p + ".esc_plk", cfg["ocab_esc_pdim"], cfg["ocab_esc_kernel"], C, dt, dev)
+                oc["esc"].aggr = self._lin(sd, *oc["esc"].aggr_keys)
             L["ocab"] = oc
             L["conv"] = P(f"layers.{g}.conv.weight", f"layers.{g}.conv.bias")
             self.layers.append(L)
@@ -171,7 +191,7 @@ class HATEngine:
         C, dev, T = self.C, self.dev, self.tdt
         N = H * W
         mid = self.layers[0]["habs"][0]["cab0"].nout if self.layers and self.layers[0]["habs"] else 8
-        hid2 = self.layers[0]["habs"][0]["fc1"].nout if self.layers and self.layers[0]["habs"] else 4 * C
+        hid2 = 2 * int(C * self.cfg["mlp_ratio"])  # fc1 width of GatedDconvFFN (hat_arch.py:99-100)
         z = lambda *shape, dtype=T: torch.zeros(*shape, dtype=dtype, device=dev)
         f = torch.float32
         w = {
@@ -260,7 +280,7 @@ class HATEngine:
                               float(cfg["conv_scale"]), w["eca_tmp"], w["scale"], B=B, C_=C)
                 self._esc_lk(esc, w, w["n"], B, H, W, nblk)
                 # t = t + aggr(cat(y16, n[pdim:])) + conv_scale * eca * c2                :236
-                ops.conv(esc.aggr, w["n"], tB, **geo, ldx=ldc, ldo=C, out_mode=O_NHWC_F32, x0=w["y16"], c_split=esc.pdim,
+                self._run_lin(esc.aggr, w["n"], tB, **geo, ldx=ldc, ldo=C, out_mode=O_NHWC_F32, x0=w["y16"], c_split=esc.pdim,
                          ldx0=16, r1=t, ldr1=C, r2=w["c2"], ldr2=ldc, r2scale=w["scale"], r2scale_bstride=hb["cab2"].npad)
                 if "ffn" in hb:  # fused LN2 + fc1 + dw3x3 + gate + fc2 + residual (+ the next block's LayerNorm)
                     if i + 1 < len(L["habs"]):
@@ -273,10 +293,10 @@ class HATEngine:
                 else:
                     ln(tB, w["n"], hb["n2"])
                     hid2 = hb["fc1"].nout
-                    ops.conv(hb["fc1"], w["n"], w["u"], **geo, ldx=ldc, ldo=w["u"].shape[2])
+                    self._run_lin(hb["fc1"], w["n"], w["u"], **geo, ldx=ldc, ldo=w["u"].shape[2])
                     ops.dwconv_gate(w["u"], hb["dw_w"], hb["dw_b"], w["g"], B=B, H=H, W=W, hid=hid2 // 2, ldu=w["u"].shape[2],
                                     ldo=w["g"].shape[2], dtype=dt)
-                    ops.conv(hb["fc2"], w["g"], tB, **geo, ldx=w["g"].shape[2], ldo=C, out_mode=O_NHWC_F32, r1=tB, ldr1=C)
+                    self._run_lin(hb["fc2"], w["g"], tB, **geo, ldx=w["g"].shape[2], ldo=C, out_mode=O_NHWC_F32, r1=tB, ldr1=C)
                     t, have_n = tB, False
             esc = oc.get("esc")  # OCAB                                                    :326-393
             if not have_n:
@@ -285,17 +305,17 @@ class HATEngine:
             kv_src = w["n"]
             if esc is not None:  # K/V from ESC(LN(x))                                     :336-344
                 self._esc_lk(esc, w, w["n"], B, H, W, nblk)
-                ops.conv(esc.aggr, w["n"], w["yesc"], **geo, ldx=ldc, ldo=ldc, x0=w["y16"], c_split=esc.pdim, ldx0=16)
+                self._run_lin(esc.aggr, w["n"], w["yesc"], **geo, ldx=ldc, ldo=ldc, x0=w["y16"], c_split=esc.pdim, ldx0=16)
                 kv_src = w["yesc"]
-            ops.conv(oc["q"], w["n"], w["q"], **geo, ldx=ldc, ldo=ldc)
-            ops.conv(oc["kv"], kv_src, w["kv"], **geo, ldx=ldc, ldo=w["kv"].shape[2])
+            self._run_lin(oc["q"], w["n"], w["q"], **geo, ldx=ldc, ldo=ldc)
+            self._run_lin(oc["kv"], kv_src, w["kv"], **geo, ldx=ldc, ldo=w["kv"].shape[2])
             ops.ocab_attention(w["q"], w["kv"], oc["bias_rot"], w["ao"], B=B, H=H, W=W, C_=C, heads=L["heads"], ws=ws,
                                wse=self.wse, ldq=ldc, ldkv=w["kv"].shape[2], ldo=ldc, dtype=dt)
             tout = tB if t is tA else t  # never write the RHAG input buffer
-            ops.conv(oc["proj"], w["ao"], tout, **geo, ldx=ldc, ldo=C, out_mode=O_NHWC_F32, r1=t, ldr1=C)
+            self._run_lin(oc["proj"], w["ao"], tout, **geo, ldx=ldc, ldo=C, out_mode=O_NHWC_F32, r1=t, ldr1=C)
             ln(tout, w["n"], oc["n2"])
-            ops.conv(oc["mlp0"], w["n"], w["g"], **geo, ldx=ldc, ldo=w["g"].shape[2], act=ACT_GELU)
-            ops.conv(oc["mlp2"], w["g"], tout, **geo, ldx=w["g"].shape[2], ldo=C, out_mode=O_NHWC_F32, r1=tout, ldr1=C)
+            self._run_lin(oc["mlp0"], w["n"], w["g"], **geo, ldx=ldc, ldo=w["g"].shape[2], act=ACT_GELU)
+            self._run_lin(oc["mlp2"], w["g"], tout, **geo, ldx=w["g"].shape[2], ldo=C, out_mode=O_NHWC_F32, r1=tout, ldr1=C)
             # RHAG tail: conv3x3 + group residual, written over the group input             :556
             ops.conv(L["conv"], tout, tA, **geo, ldx=C, ldo=C, x_mode=X_NHWC_F32, out_mode=O_NHWC_F32, r1=tA, ldr1=C)
         ln(tA, w["n"], self.norm)  # final LN                                             :844

@@ -67,11 +67,12 @@ _TNAME = {HAT_F32: "float", HAT_BF16: "__bf16"}
 
 class PackedConv:
     """Packed weights of one conv/linear layer (see HatConvDesc in include/hat_mi355x.h)."""
-    __slots__ = ("w", "bias", "ksize", "cin", "kpad", "nt", "n_slices", "nout", "w_bstride")
+    __slots__ = ("w", "bias", "ksize", "cin", "kpad", "nt", "n_slices", "nout", "w_bstride", "frag")
 
-    def __init__(self, w, bias, ksize, cin, kpad, nt, n_slices, nout, w_bstride=0):
+    def __init__(self, w, bias, ksize, cin, kpad, nt, n_slices, nout, w_bstride=0, frag=False):
         self.w, self.bias, self.ksize, self.cin, self.kpad = w, bias, ksize, cin, kpad
         self.nt, self.n_slices, self.nout, self.w_bstride = nt, n_slices, nout, w_bstride
+        self.frag = frag  # True: MFMA-fragment order for hat_linear; False: [Npad][Kpad] rows for hat_conv
 
     @property
     def npad(self):
@@ -312,3 +313,55 @@ def ffn(pf: PackedFFN, t_in, t_out, ln_g, ln_b, *, B: int, H: int, W: int, dtype
         d.gap_out, d.gap_c = (_ptr(gap_out) if gap_c else None), gap_c
     flops = B * H * W * (2.0 * pf.C * 2 * pf.hid + 2.0 * 9 * 2 * pf.hid + 2.0 * pf.hid * pf.C)
     _timed(f"ffn_kernel<{_TNAME[dtype]}>", flops, lambda: _lib.check(lib.hat_ffn(C.byref(d), _stream()), "hat_ffn"))
+
+
+# ------------------------------------------------------------------------------------------------
+# pointwise linear layers (hat_linear): fragment-packed weights, weight-stationary streaming GEMM
+# ------------------------------------------------------------------------------------------------
+_PW_SHAPES = {(9, 5), (9, 9), (12, 6), (12, 12), (4, 1), (4, 2)}  # (nt, ceil(Cin/32)) instantiated in hat_pw.hip
+
+
+def linear_supported(nout: int, cin: int, dtype: int) -> bool:
+    nt, _ = choose_nt(nout)
+    ks = -(-cin // 32)
+    lds = nt * ks * 64 * 8 * (2 if dtype == HAT_BF16 else 4)
+    return (nt, ks) in _PW_SHAPES and lds <= 163840 and cin % 4 == 0
+
+
+def pack_linear_weight(weight: torch.Tensor, bias: Optional[torch.Tensor], dtype: int, device, scale: float = 1.0) -> PackedConv:
+    """weight (O, I) -> MFMA A-fragment order [n_slices][nt][ceil(I/32)][64 lanes][8] for hat_linear."""
+    w = weight.detach().to(torch.float32).cpu().reshape(weight.shape[0], -1) * scale
+    o, i = w.shape
+    b = (torch.zeros(o) if bias is None else bias.detach().to(torch.float32).cpu()) * scale
+    nt, n_slices = choose_nt(o)
+    ks = -(-i // 32)
+    npad = nt * 16 * n_slices
+    wp = torch.zeros(npad, ks * 32)
+    wp[:o, :i] = w
+    lane = torch.arange(64)
+    row = (torch.arange(n_slices)[:, None, None, None, None] * nt * 16 + torch.arange(nt)[None, :, None, None, None] * 16
+           + (lane & 15)[None, None, None, :, None]).expand(n_slices, nt, ks, 64, 8)
+    col = (torch.arange(ks)[None, None, :, None, None] * 32 + 8 * (lane >> 4)[None, None, None, :, None]
+           + torch.arange(8)[None, None, None, None, :]).expand(n_slices, nt, ks, 64, 8)
+    wf = wp[row, col].to(TORCH_DTYPE[dtype]).contiguous().to(device)
+    bp = torch.zeros(npad)
+    bp[:o] = b
+    return PackedConv(wf, bp.to(device), 1, i, ks * 32, nt, n_slices, o)
+
+
+def linear(pw: PackedConv, x: torch.Tensor, out: torch.Tensor, *, B: int, H: int, W: int, dtype: int, ldx: int, ldo: int,
+           out_mode: int = O_NHWC_T, act: int = ACT_NONE, n_store: Optional[int] = None, x0: Optional[torch.Tensor] = None,
+           c_split: int = 0, ldx0: int = 0, r1: Optional[torch.Tensor] = None, ldr1: int = 0, r2: Optional[torch.Tensor] = None,
+           ldr2: int = 0, r2scale: Optional[torch.Tensor] = None, r2scale_bstride: int = 0):
+    lib = _lib.load()
+    d = HatConvDesc()
+    d.x, d.x0, d.w, d.bias, d.out = _ptr(x), _ptr(x0), _ptr(pw.w), _ptr(pw.bias), _ptr(out)
+    d.r1, d.r2, d.r2scale = _ptr(r1), _ptr(r2), _ptr(r2scale)
+    d.B, d.H, d.W, d.Cin, d.ldx, d.x_mode = B, H, W, pw.cin, ldx, X_NHWC_T
+    d.c_split, d.ldx0, d.ksize, d.Kpad, d.nt, d.n_slices = c_split, ldx0, 1, pw.kpad, pw.nt, pw.n_slices
+    d.n_store = pw.nout if n_store is None else n_store
+    d.ldo, d.out_mode, d.act, d.ldr1, d.ldr2, d.r2scale_bstride, d.dtype = ldo, out_mode, act, ldr1, ldr2, r2scale_bstride, dtype
+    flops = 2.0 * B * H * W * pw.cin * pw.nout
+    _timed(f"pw_kernel<{_TNAME[dtype]}, {pw.nt}, {pw.kpad // 32}>", flops,
+           lambda: _lib.check(lib.hat_linear(C.byref(d), _stream()), f"hat_linear(Cin={pw.cin}, N={pw.nout})"),
+           tag=f"lin {pw.cin}->{pw.nout} {H}x{W} o{out_mode}{' r1' if r1 is not None else ''}{' r2' if r2 is not None else ''}")

@@ -395,3 +395,49 @@ def test_fused_ffn(dtype, geom):
     ops.ffn(pf, tin, tout2, dv("n2.weight"), dv("n2.bias"), B=B, H=H, W=W, dtype=dt)
     torch.cuda.synchronize()
     assert torch.equal(tout, tout2)
+
+
+# ------------------------------------------------------------------------------------------------
+LIN_CASES = [("aggr144", 144, 144), ("kv288", 144, 288), ("mlp2_288", 288, 144), ("lin180", 180, 180), ("mlp360", 360, 180),
+             ("kv360", 180, 360), ("tiny24", 24, 48), ("tiny48", 48, 24)]
+
+
+@pytest.mark.parametrize("dtype", DT)
+@pytest.mark.parametrize("case", LIN_CASES, ids=[c[0] for c in LIN_CASES])
+def test_linear_streaming(case, dtype):
+    """hat_linear (weight-stationary streaming GEMM): plain, GELU, fp32 residual in place, split source + scaled T residual."""
+    name, Cin, Cout = case
+    dev, ops = _dev(), _ops()
+    dt = ops.DTYPE_CODE[dtype]
+    tdt = ops.TORCH_DTYPE[dt]
+    if not ops.linear_supported(Cout, Cin, dt):
+        pytest.skip("shape not instantiated in hat_linear (the engine uses hat_conv for it)")
+    B, H, W = 2, 19, 27  # 1026 pixels: not a multiple of 16, exercises the tail tile
+    x = q(rnd(name + "x", (B, H, W, Cin)), dtype)
+    wgt = q(rnd(name + "w", (Cout, Cin), std=Cin ** -0.5), dtype)
+    bias = rnd(name + "b", (Cout,), std=0.1)
+    pw = ops.pack_linear_weight(wgt, bias, dt, dev)
+    ldx, ldo = _r8(Cin), _r8(Cout)
+    xd = to_dev(x, ldx, tdt, dev)
+    lin = F.linear(x.double(), wgt.double(), bias.double())
+    out = torch.zeros(B, H * W, ldo, dtype=tdt, device=dev)
+    ops.linear(pw, xd, out, B=B, H=H, W=W, dtype=dt, ldx=ldx, ldo=ldo, act=ops.ACT_GELU)
+    torch.cuda.synchronize()
+    ref = F.gelu(lin)
+    check(out[:, :, :Cout].float().reshape(B, H, W, Cout), q(ref.float(), dtype).double() if dtype == "bf16" else ref, dtype, name + " gelu")
+    # fp32 residual written in place, plus a scaled T residual, plus a split source for the first 8 channels
+    c_split = 8
+    x0 = q(rnd(name + "x0", (B, H, W, c_split)), dtype)
+    r1 = rnd(name + "r1", (B, H, W, Cout))
+    r2 = q(rnd(name + "r2", (B, H, W, Cout)), dtype)
+    sc = rnd(name + "sc", (B, Cout), std=0.3)
+    xin = torch.cat([x0, x[..., c_split:]], -1)
+    ref2 = F.linear(xin.double(), wgt.double(), bias.double()) + r1.double() + sc.double()[:, None, None, :] * r2.double()
+    rd = r1.reshape(B, H * W, Cout).to(dev).contiguous()
+    scd = torch.zeros(B, pw.npad, device=dev)
+    scd[:, :Cout] = sc.to(dev)
+    ops.linear(pw, xd, rd, B=B, H=H, W=W, dtype=dt, ldx=ldx, ldo=Cout, out_mode=ops.O_NHWC_F32, x0=to_dev(x0, c_split, tdt, dev),
+               c_split=c_split, ldx0=c_split, r1=rd, ldr1=Cout, r2=to_dev(r2, ldo, tdt, dev), ldr2=ldo, r2scale=scd,
+               r2scale_bstride=pw.npad)
+    torch.cuda.synchronize()
+    check(rd.reshape(B, H, W, Cout), ref2, dtype, name + " residual epilogue", f32_tol=3e-5)
