@@ -49,7 +49,7 @@ enum { HAT_O_NHWC_T = 0, HAT_O_NHWC_F32 = 1, HAT_O_PIXSHUF_T = 2, HAT_O_NCHW_F32
  * latter folded into per-sample weights by hat_esc_weights).
  *
  * Wp is packed [n_slices * nt * 16][Kpad] in T with K index = tap * Cin_p + ci,
- * Cin_p = round_up(Cin, 8), Kpad = round_up(ksize^2 * Cin_p, KC), KC = 64 (bf16) / 32 (f32);
+ * Cin_p = round_up(Cin, 8), Kpad = round_up(ksize^2 * Cin_p, KC), KC = 64 (bf16) / 32 (f32), x3 when nt == 1;
  * zero padded.  epi: v = acc + bias[n]; v = act(v); v += r1[p, n] (fp32, optional);
  * v += r2scale[n] * r2[p, n] (T, optional); store by out_mode; optional per-tile column sums
  * of v (for the ECA global average pool, hat_arch.py:73).
@@ -95,6 +95,16 @@ int hat_conv(const HatConvDesc* d, void* stream);
  * Returns HAT_EUNSUPPORTED for (nt, Cin) pairs that are not instantiated: call hat_conv instead.
  */
 int hat_linear(const HatConvDesc* d, void* stream);
+
+/*
+ * 3x3 convolution (zero padding 1) whose whole weight slice fits in LDS — the two CAB convolutions
+ * (hat_arch.py:84,86) — in the same free-running structure: neighbour pixels are gathered straight from global
+ * memory.  Same descriptor as hat_conv (ksize 3, n_slices 1, channel-last T input, no residuals), weights
+ * FRAGMENT packed like hat_linear with K index = tap * Cin_p + ci.  Optional colsum is [B][groups][nt*16]
+ * (one row per workgroup), groups from hat_conv3x3_small_groups().  HAT_EUNSUPPORTED: use hat_conv.
+ */
+int hat_conv3x3_small_groups(const HatConvDesc* d, int32_t* groups_out);
+int hat_conv3x3_small(const HatConvDesc* d, void* stream);
 
 /*
  * LayerNorm over the channel dimension (eps 1e-5, affine), fp32 in -> T or fp32 out

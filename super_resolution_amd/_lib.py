@@ -63,6 +63,8 @@ SIGNATURES = {
                                 C.POINTER(C.c_int64)]),
     "hat_conv": (C.c_int, [C.POINTER(HatConvDesc), C.c_void_p]),
     "hat_linear": (C.c_int, [C.POINTER(HatConvDesc), C.c_void_p]),
+    "hat_conv3x3_small_groups": (C.c_int, [C.POINTER(HatConvDesc), C.POINTER(C.c_int32)]),
+    "hat_conv3x3_small": (C.c_int, [C.POINTER(HatConvDesc), C.c_void_p]),
     "hat_ffn_tiles": (C.c_int, [C.POINTER(HatFfnDesc), C.POINTER(C.c_int32)]),
     "hat_ffn": (C.c_int, [C.POINTER(HatFfnDesc), C.c_void_p]),
     "hat_layernorm_blocks": (C.c_int, []),

@@ -146,6 +146,157 @@ int launch_pw(const HatConvDesc& d, hipStream_t s) {
     return hat_check_launch();
 }
 
+// ---------------------------------------------------------------------------------------------------------
+// 3x3 convolutions whose whole weight slice fits in LDS (CAB: C -> C/cr and C/cr -> C, hat_arch.py:84,86), same
+// free-running structure: the B fragment of k-step ks is the 16-byte group ci..ci+7 of the NEIGHBOUR pixel of
+// tap (32 ks + 8 g) / Cin_p, gathered straight from global memory (L1/L2 serve the 9-fold re-reads); neighbours
+// outside the image read a zero page.  Optional per-workgroup column sums (ECA pooling, hat_arch.py:73).
+// ---------------------------------------------------------------------------------------------------------
+__device__ __attribute__((aligned(16))) unsigned hat_zero_page[16] = {0};
+
+template <typename T, int NT, int KS, int CINP, int WAVES, int MINW>
+__global__ __launch_bounds__(WAVES * 64, MINW) void tap3_kernel(const HatConvDesc d, int tiles) {
+    using M = MT<T>;
+    using frag_t = typename M::frag_t;
+    constexpr int nthr = WAVES * 64;
+    constexpr int GRP = 8;  // B fragments gathered before their MFMAs are issued
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    T* Wl = reinterpret_cast<T*>(smem);  // [NT][KS][64 lanes][8]
+    const int tid = threadIdx.x, lane = tid & 63, g = lane >> 4, c16 = lane & 15;
+    const int wave = tid >> 6;
+    const int b = blockIdx.z;
+    const T* wg = reinterpret_cast<const T*>(d.w);
+    for (int i = tid; i < NT * KS * 64 * (int)sizeof(T) / 2; i += nthr)
+        *reinterpret_cast<u32x4*>(smem + (size_t)i * 16) = *reinterpret_cast<const u32x4*>(reinterpret_cast<const char*>(wg) + (size_t)i * 16);
+    __syncthreads();
+
+    const int H = d.H, W = d.W, Cin = d.Cin;
+    const long HW = (long)H * W;
+    const T* xb = reinterpret_cast<const T*>(d.x) + (size_t)b * HW * d.ldx;
+    const T* zero = reinterpret_cast<const T*>(hat_zero_page);
+    f32x4 csum[NT];
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) csum[nt] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    const int stride = gridDim.x * WAVES;
+    for (int tile = blockIdx.x * WAVES + wave; tile < tiles; tile += stride) {
+        const long p = (long)tile * 16 + c16;
+        const bool pv = p < HW;
+        const int y = (int)(p / W), x = (int)(p - (long)y * W);
+        f32x4 acc[NT];
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) acc[nt] = f32x4{0.f, 0.f, 0.f, 0.f};
+        int wofs = lane * 8;
+        asm volatile("" : "+v"(wofs));  // keep the loop-invariant LDS weight reads inside the loop (no hoist + spill)
+#pragma unroll
+        for (int k0 = 0; k0 < KS; k0 += GRP) {
+            frag_t bf[GRP];
+#pragma unroll
+            for (int kk = 0; kk < GRP; ++kk) {
+                const int ks = k0 + kk;
+                if (ks < KS) {
+                    const int k = 32 * ks + 8 * g;
+                    const int tap = k / CINP, ci = k - tap * CINP;
+                    const int dy = tap / 3 - 1, dx = tap - (tap / 3) * 3 - 1;
+                    const int yy = y + dy, xx = x + dx;
+                    const bool inb = pv && tap < 9 && ci < Cin && yy >= 0 && yy < H && xx >= 0 && xx < W;
+                    const T* src = inb ? xb + ((size_t)yy * W + xx) * d.ldx + ci : zero;
+                    bf[kk] = M::load(src);
+                }
+            }
+#pragma unroll
+            for (int kk = 0; kk < GRP; ++kk) {
+                const int ks = k0 + kk;
+                if (ks < KS) {
+#pragma unroll
+                    for (int nt = 0; nt < NT; ++nt) {
+                        const frag_t af = M::load(Wl + (size_t)(nt * KS + ks) * 512 + wofs);
+                        acc[nt] = M::mma(af, bf[kk], acc[nt]);
+                    }
+                }
+            }
+        }
+        if (pv) {
+            const size_t pix = (size_t)b * HW + p;
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) {
+                const int n = nt * 16 + 4 * g;
+                if (n < d.n_store) {
+                    f32x4 v = acc[nt] + *reinterpret_cast<const f32x4*>(d.bias + n);
+                    if (d.act == HAT_ACT_GELU) {
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) v[r] = gelu_erf(v[r]);
+                    } else if (d.act == HAT_ACT_LRELU) {
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) v[r] = v[r] >= 0.f ? v[r] : 0.01f * v[r];
+                    }
+                    csum[nt] += v;
+                    if (d.out_mode == HAT_O_NHWC_T) Vec4<T>::store(reinterpret_cast<T*>(d.out) + pix * d.ldo + n, v);
+                    else *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(d.out) + pix * d.ldo + n) = v;
+                }
+            }
+        }
+    }
+    if (d.colsum != nullptr) {  // per-workgroup column sums, fixed reduction order: lanes (pixels), then waves
+        __syncthreads();        // every wave is done with the weights: reuse LDS as scratch
+        float* red = reinterpret_cast<float*>(smem);
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                float sv = csum[nt][r];
+                sv += __shfl_xor(sv, 1); sv += __shfl_xor(sv, 2); sv += __shfl_xor(sv, 4); sv += __shfl_xor(sv, 8);
+                if (c16 == 0) red[wave * (NT * 16) + nt * 16 + 4 * g + r] = sv;
+            }
+        }
+        __syncthreads();
+        for (int n = tid; n < NT * 16; n += nthr) {
+            float sv = 0.f;
+#pragma unroll
+            for (int w = 0; w < WAVES; ++w) sv += red[w * (NT * 16) + n];
+            d.colsum[((size_t)b * gridDim.x + blockIdx.x) * (NT * 16) + n] = sv;
+        }
+    }
+}
+
+template <typename T, int NT, int KS, int CINP>
+int launch_tap3(const HatConvDesc& d, hipStream_t s, int32_t* groups_out) {
+    const size_t lds = (size_t)NT * KS * 64 * 8 * sizeof(T);
+    if (lds > HAT_LDS_MAX / 2) return HAT_EUNSUPPORTED;
+    const long hw = (long)d.H * d.W;
+    const int tiles = (int)((hw + 15) / 16);
+    const int wgs_per_cu = (int)(HAT_LDS_MAX / lds) >= 3 ? 3 : 2;
+    int gx = 256 * wgs_per_cu;
+    if (gx > (tiles + 3) / 4) gx = (tiles + 3) / 4;
+    if (groups_out) { *groups_out = gx; return 0; }
+    dim3 grid(gx, 1, d.B);
+    if (wgs_per_cu == 3) {
+        auto kern = tap3_kernel<T, NT, KS, CINP, 4, 3>;
+        HAT_LAUNCH(kern, grid, dim3(256), lds, s, d, tiles);
+    } else {
+        auto kern = tap3_kernel<T, NT, KS, CINP, 4, 2>;
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return (int)e;
+        HAT_LAUNCH(kern, grid, dim3(256), lds, s, d, tiles);
+    }
+    return hat_check_launch();
+}
+
+int tap3_dispatch(const HatConvDesc& d, hipStream_t s, int32_t* groups_out) {
+    if (d.ksize != 3 || d.n_slices != 1 || d.x_mode != HAT_X_NHWC_T || d.x0 || d.r1 || d.r2) return HAT_EUNSUPPORTED;
+    if (d.out_mode != HAT_O_NHWC_T && d.out_mode != HAT_O_NHWC_F32) return HAT_EUNSUPPORTED;
+    const int cinp = (d.Cin + 7) & ~7;
+#define HAT_T3(TT)                                                                                            \
+    if (d.nt == 1 && cinp == 144) return launch_tap3<TT, 1, 41, 144>(d, s, groups_out);  /* CAB conv 144 -> 6 */   \
+    if (d.nt == 9 && cinp == 8) return launch_tap3<TT, 9, 3, 8>(d, s, groups_out);       /* CAB conv 6 -> 144 */   \
+    if (d.nt == 1 && cinp == 24) return launch_tap3<TT, 1, 7, 24>(d, s, groups_out);     /* tiny: 24 -> 8 */       \
+    if (d.nt == 4 && cinp == 8) return launch_tap3<TT, 4, 3, 8>(d, s, groups_out);       /* tiny: 8 -> 24 */
+    if (d.dtype == HAT_BF16) { HAT_T3(bf16_t) }
+    else if (d.dtype == HAT_F32) { HAT_T3(float) }
+#undef HAT_T3
+    return HAT_EUNSUPPORTED;
+}
+
 }  // namespace
 
 extern "C" int hat_linear(const HatConvDesc* dp, void* stream) {
@@ -171,4 +322,21 @@ extern "C" int hat_linear(const HatConvDesc* dp, void* stream) {
     else return HAT_EINVAL;
 #undef HAT_PW_CASE
     return HAT_EUNSUPPORTED;  // shapes not instantiated here: use hat_conv (ksize 1)
+}
+
+/* 3x3 convolution with the whole weight slice resident in LDS (see tap3_kernel); weights fragment packed like
+ * hat_linear with K index = tap * Cin_p + ci.  colsum (optional) is [B][groups][nt*16] with groups from
+ * hat_conv3x3_small_groups().  HAT_EUNSUPPORTED for shapes that are not instantiated: use hat_conv. */
+extern "C" int hat_conv3x3_small_groups(const HatConvDesc* dp, int32_t* groups_out) {
+    if (!dp || !groups_out) return HAT_EINVAL;
+    return tap3_dispatch(*dp, nullptr, groups_out);
+}
+
+extern "C" int hat_conv3x3_small(const HatConvDesc* dp, void* stream) {
+    if (!dp) return HAT_EINVAL;
+    const HatConvDesc& d = *dp;
+    if (!d.x || !d.w || !d.bias || !d.out || d.B < 1 || d.H < 1 || d.W < 1) return HAT_EINVAL;
+    const int vec = d.dtype == HAT_BF16 ? 8 : 4;
+    if (d.ldx % vec || d.n_store % 4 || d.ldo % 4 || d.n_store > d.nt * 16) return HAT_EINVAL;
+    return tap3_dispatch(d, reinterpret_cast<hipStream_t>(stream), nullptr);
 }

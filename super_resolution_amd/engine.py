@@ -48,7 +48,7 @@ class _ESC:
         # static large-kernel filter packed in fp32 [16][Kpad]; hat_esc_weights adds the dynamic
         # depthwise 3x3 on the diagonal of the central taps and casts to T per forward
         lk = ops.pack_conv_weight(sd[plk_key], None, ops.HAT_F32, dev, nt=1)
-        kc = ops.KC[dtype]
+        kc = ops.KC[dtype] * 3  # nt == 1 chunk length (hat_conv.hip)
         self.kpad = -(-(ksize * ksize * _r8(pdim)) // kc) * kc
         plk = torch.zeros(16, self.kpad, **f32)
         plk[:, :min(self.kpad, lk.kpad)] = lk.w[:16, :min(self.kpad, lk.kpad)]
@@ -98,6 +98,13 @@ class HATEngine:
         pw.frag = False
         return pw
 
+    def _c3(self, sd, wkey, bkey):
+        """Pack a CAB 3x3 conv for hat_conv3x3_small (weights resident in LDS) when instantiated, else for hat_conv."""
+        w = sd[wkey]
+        if ops.conv3x3_small_supported(w.shape[0], w.shape[1], self.dtype):
+            return ops.pack_linear_weight(w, sd[bkey], self.dtype, self.dev)
+        return ops.pack_conv_weight(w, sd[bkey], self.dtype, self.dev)
+
     def _run_lin(self, pw, x, out, **kw):
         (ops.linear if pw.frag else ops.conv)(pw, x, out, **kw)
 
@@ -121,8 +128,8 @@ class HATEngine:
                     "n1": (vec(p + ".norm1.weight"), vec(p + ".norm1.bias")),
                     "n2": (vec(p + ".norm2.weight"), vec(p + ".norm2.bias")),
                     "esc": _ESC(sd, p + ".esc_attn.core", p + ".esc_attn.plk_filter", cfg["esc_pdim"], cfg["esc_kernel"], C, dt, dev),
-                    "cab0": P(p + ".conv_block.cab.0.weight", p + ".conv_block.cab.0.bias"),
-                    "cab2": P(p + ".conv_block.cab.2.weight", p + ".conv_block.cab.2.bias"),
+                    "cab0": self._c3(sd, p + ".conv_block.cab.0.weight", p + ".conv_block.cab.0.bias"),
+                    "cab2": self._c3(sd, p + ".conv_block.cab.2.weight", p + ".conv_block.cab.2.bias"),
                     "eca_w": vec(p + ".conv_block.cab.3.conv.weight").reshape(-1),
                 }
                 hb["esc"].aggr = self._lin(sd, *hb["esc"].aggr_keys)
@@ -210,7 +217,7 @@ class HATEngine:
             w["yesc"] = z(B, N, _r8(C))
         cab2 = self.layers[0]["habs"][0]["cab2"] if self.layers and self.layers[0]["habs"] else None
         if cab2 is not None:
-            tiles = ops.conv_tiles(cab2, H, W, self.dtype)
+            tiles = ops.conv3x3_small_groups(cab2, B, H, W, self.dtype) if cab2.frag else ops.conv_tiles(cab2, H, W, self.dtype)
             w["tiles"] = tiles
             w["colsum"] = z(B, tiles, cab2.npad, dtype=f)
         h, wd = H, W
@@ -274,8 +281,10 @@ class HATEngine:
                     ln(t, w["n"], hb["n1"], gap_c=esc.pdim)
                     nblk = LNB
                 mid = hb["cab0"].nout
-                ops.conv(hb["cab0"], w["n"], w["c1"], **geo, ldx=ldc, ldo=_r8(mid), act=ACT_GELU, n_store=_r4(mid))
-                ops.conv(hb["cab2"], w["c1"], w["c2"], **geo, ldx=_r8(mid), ldo=ldc, colsum=w["colsum"])
+                c3 = ops.conv3x3_small if hb["cab0"].frag else ops.conv
+                c3(hb["cab0"], w["n"], w["c1"], **geo, ldx=ldc, ldo=_r8(mid), act=ACT_GELU, n_store=_r4(mid))
+                c3 = ops.conv3x3_small if hb["cab2"].frag else ops.conv
+                c3(hb["cab2"], w["c1"], w["c2"], **geo, ldx=_r8(mid), ldo=ldc, colsum=w["colsum"])
                 ops.eca_scale(w["colsum"], w["tiles"], hb["cab2"].npad, N, hb["eca_w"], hb["eca_w"].numel(),
                               float(cfg["conv_scale"]), w["eca_tmp"], w["scale"], B=B, C_=C)
                 self._esc_lk(esc, w, w["n"], B, H, W, nblk)

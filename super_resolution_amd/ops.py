@@ -104,13 +104,13 @@ def pack_conv_weight(weight: torch.Tensor, bias: Optional[torch.Tensor], dtype: 
     if out_perm is not None:
         w, b = w[out_perm], b[out_perm]
     cin_p = (i + 7) // 8 * 8
-    kc = KC[dtype]
     k = kh * kw * cin_p
-    kpad = -(-k // kc) * kc
     if nt is None:
         nt, n_slices = choose_nt(o)
     else:
         n_slices = -(-o // (16 * nt))
+    kc = KC[dtype] * (3 if nt == 1 else 1)  # one-n-tile layers use a 3x longer weight chunk (hat_conv.hip)
+    kpad = -(-k // kc) * kc
     npad = nt * 16 * n_slices
     wp = torch.zeros(npad, kpad, dtype=torch.float32)
     wt = torch.zeros(o, kh * kw, cin_p)
@@ -329,8 +329,17 @@ def linear_supported(nout: int, cin: int, dtype: int) -> bool:
 
 
 def pack_linear_weight(weight: torch.Tensor, bias: Optional[torch.Tensor], dtype: int, device, scale: float = 1.0) -> PackedConv:
-    """weight (O, I) -> MFMA A-fragment order [n_slices][nt][ceil(I/32)][64 lanes][8] for hat_linear."""
-    w = weight.detach().to(torch.float32).cpu().reshape(weight.shape[0], -1) * scale
+    """weight (O, I) -> MFMA A-fragment order [n_slices][nt][ceil(I/32)][64 lanes][8] for hat_linear.
+    A conv weight (O, I, k, k) is first flattened to K = tap * Cin_p + ci (hat_conv3x3_small)."""
+    w = weight.detach().to(torch.float32).cpu()
+    ksize, cin = 1, None
+    if w.dim() == 4 and w.shape[-1] > 1:
+        o_, i_, ksize, _ = w.shape
+        cin, cin_p = i_, (i_ + 7) // 8 * 8
+        wt = torch.zeros(o_, ksize * ksize, cin_p)
+        wt[:, :, :i_] = w.permute(0, 2, 3, 1).reshape(o_, ksize * ksize, i_)
+        w = wt.reshape(o_, -1)
+    w = w.reshape(w.shape[0], -1) * scale
     o, i = w.shape
     b = (torch.zeros(o) if bias is None else bias.detach().to(torch.float32).cpu()) * scale
     nt, n_slices = choose_nt(o)
@@ -346,7 +355,7 @@ def pack_linear_weight(weight: torch.Tensor, bias: Optional[torch.Tensor], dtype
     wf = wp[row, col].to(TORCH_DTYPE[dtype]).contiguous().to(device)
     bp = torch.zeros(npad)
     bp[:o] = b
-    return PackedConv(wf, bp.to(device), 1, i, ks * 32, nt, n_slices, o)
+    return PackedConv(wf, bp.to(device), ksize, (i if cin is None else cin), ks * 32, nt, n_slices, o, frag=True)
 
 
 def linear(pw: PackedConv, x: torch.Tensor, out: torch.Tensor, *, B: int, H: int, W: int, dtype: int, ldx: int, ldo: int,
@@ -365,3 +374,41 @@ def linear(pw: PackedConv, x: torch.Tensor, out: torch.Tensor, *, B: int, H: int
     _timed(f"pw_kernel<{_TNAME[dtype]}, {pw.nt}, {pw.kpad // 32}>", flops,
            lambda: _lib.check(lib.hat_linear(C.byref(d), _stream()), f"hat_linear(Cin={pw.cin}, N={pw.nout})"),
            tag=f"lin {pw.cin}->{pw.nout} {H}x{W} o{out_mode}{' r1' if r1 is not None else ''}{' r2' if r2 is not None else ''}")
+
+
+_T3_SHAPES = {(1, 144), (9, 8), (1, 24), (4, 8)}  # (nt, Cin_p) instantiated in tap3_kernel
+
+
+def conv3x3_small_supported(nout: int, cin: int, dtype: int = HAT_BF16) -> bool:
+    nt, n_slices = choose_nt(nout)
+    cin_p = (cin + 7) // 8 * 8
+    lds = nt * (-(-9 * cin_p // 32)) * 64 * 8 * (2 if dtype == HAT_BF16 else 4)
+    return (nt, cin_p) in _T3_SHAPES and n_slices == 1 and lds <= 81920
+
+
+def _c3_desc(pw, B, H, W, dtype, ldx):
+    d = HatConvDesc()
+    d.B, d.H, d.W, d.Cin, d.ldx, d.x_mode = B, H, W, pw.cin, ldx, X_NHWC_T
+    d.ksize, d.Kpad, d.nt, d.n_slices, d.dtype = 3, pw.kpad, pw.nt, 1, dtype
+    return d
+
+
+def conv3x3_small_groups(pw: PackedConv, B: int, H: int, W: int, dtype: int) -> int:
+    lib = _lib.load()
+    d = _c3_desc(pw, B, H, W, dtype, 8)
+    n = C.c_int32(0)
+    _lib.check(lib.hat_conv3x3_small_groups(C.byref(d), C.byref(n)), "hat_conv3x3_small_groups")
+    return n.value
+
+
+def conv3x3_small(pw: PackedConv, x, out, *, B: int, H: int, W: int, dtype: int, ldx: int, ldo: int, act: int = ACT_NONE,
+                  n_store: Optional[int] = None, out_mode: int = O_NHWC_T, colsum=None):
+    lib = _lib.load()
+    d = _c3_desc(pw, B, H, W, dtype, ldx)
+    d.x, d.w, d.bias, d.out, d.colsum = _ptr(x), _ptr(pw.w), _ptr(pw.bias), _ptr(out), _ptr(colsum)
+    d.n_store = pw.nout if n_store is None else n_store
+    d.ldo, d.out_mode, d.act = ldo, out_mode, act
+    flops = 2.0 * B * H * W * 9 * pw.cin * pw.nout
+    _timed(f"tap3_kernel<{_TNAME[dtype]}, {pw.nt}>", flops,
+           lambda: _lib.check(lib.hat_conv3x3_small(C.byref(d), _stream()), f"hat_conv3x3_small(Cin={pw.cin}, N={pw.nout})"),
+           tag=f"c3s {pw.cin}->{pw.nout} {H}x{W}")

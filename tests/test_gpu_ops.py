@@ -319,7 +319,7 @@ def test_esc_weights_and_eca(dtype, pdim, ks):
     for i in range(pdim):
         weff[:, i, i, c - 1:c + 2, c - 1:c + 2] += dk[:, i]
     lk = ops.pack_conv_weight(plk, None, ops.HAT_F32, dev, nt=1)
-    kc = ops.KC[dt]
+    kc = ops.KC[dt] * 3
     kpad = -(-(ks * ks * _r8(pdim)) // kc) * kc
     plkp = torch.zeros(16, kpad, device=dev)
     plkp[:, :min(kpad, lk.kpad)] = lk.w[:16, :min(kpad, lk.kpad)]
@@ -441,3 +441,32 @@ def test_linear_streaming(case, dtype):
                r2scale_bstride=pw.npad)
     torch.cuda.synchronize()
     check(rd.reshape(B, H, W, Cout), ref2, dtype, name + " residual epilogue", f32_tol=3e-5)
+
+
+@pytest.mark.parametrize("dtype", DT)
+@pytest.mark.parametrize("case", [("cab0", 144, 6, 1), ("cab2", 6, 144, 0), ("t_cab0", 24, 8, 1), ("t_cab2", 8, 24, 0)],
+                         ids=lambda c: c[0])
+def test_conv3x3_small(case, dtype):
+    """hat_conv3x3_small (CAB convs, weights resident in LDS, neighbours gathered from global) + column sums."""
+    name, Cin, Cout, act = case
+    dev, ops = _dev(), _ops()
+    dt = ops.DTYPE_CODE[dtype]
+    tdt = ops.TORCH_DTYPE[dt]
+    if not ops.conv3x3_small_supported(Cout, Cin, dt):
+        pytest.skip("weight slice does not fit half the LDS in this dtype (the engine uses hat_conv)")
+    B, H, W = 2, 24, 40
+    x = q(rnd(name + "x", (B, H, W, Cin)), dtype)
+    wgt = q(rnd(name + "w", (Cout, Cin, 3, 3), std=(9 * Cin) ** -0.5), dtype)
+    bias = rnd(name + "b", (Cout,), std=0.1)
+    ref = F.conv2d(x.permute(0, 3, 1, 2).double(), wgt.double(), bias.double(), padding=1)
+    ref = (F.gelu(ref) if act else ref).permute(0, 2, 3, 1)
+    pw = ops.pack_linear_weight(wgt, bias, dt, dev)
+    ldx, ldo = _r8(Cin), _r8(Cout)
+    out = torch.zeros(B, H * W, ldo, dtype=tdt, device=dev)
+    groups = ops.conv3x3_small_groups(pw, B, H, W, dt)
+    colsum = torch.zeros(B, groups, pw.npad, device=dev)
+    ops.conv3x3_small(pw, to_dev(x, ldx, tdt, dev), out, B=B, H=H, W=W, dtype=dt, ldx=ldx, ldo=ldo, act=act,
+                      n_store=(Cout + 3) // 4 * 4, colsum=colsum)
+    torch.cuda.synchronize()
+    check(out[:, :, :Cout].float().reshape(B, H, W, Cout), q(ref.float(), dtype).double() if dtype == "bf16" else ref, dtype, name)
+    check(colsum.sum(1)[:, :Cout] / (H * W), ref.mean((1, 2)), dtype, name + " column sums", f32_tol=3e-5)
