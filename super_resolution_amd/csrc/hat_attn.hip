@@ -163,6 +163,121 @@ __global__ __launch_bounds__(256) void ocab_attn_kernel(const T* __restrict__ q,
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------
+// Fast path: bf16, 16x16 query windows, 24x24 key windows, head_dim 24 (HAT-S and every C = 144 model).
+// Differences from the generic kernel above, all aimed at the VALU (softmax) and LDS-store bottlenecks:
+//   * K and V are staged with 16-byte pieces, V row-major [key][32] (no 2-byte transposing stores); the A
+//     operand V^T of the second MFMA is read with ds_read_b64_tr_b16 (hardware transpose);
+//   * V carries a constant-1 column at channel 24, so the softmax denominator is output row 24 of the same
+//     MFMA (it is rescaled with O for free in the online-softmax update): no VALU row sums;
+//   * the relative-position bias enters as the C operand of the S MFMA: no VALU bias adds;
+//   * p = exp2(fma(s, log2e, -m*log2e)): one FMA + one exp per score.
+// ---------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256, 2) void ocab_attn_fast_kernel(const bf16_t* __restrict__ q, const bf16_t* __restrict__ kv,
+                                                                const float* __restrict__ bias_rot, bf16_t* __restrict__ out,
+                                                                int H, int W, int C, int heads, int ldq, int ldkv, int ldo) {
+    using M = MT<bf16_t>;
+    using frag_t = M::frag_t;
+    constexpr int WS = 16, WSE = 24, D = 24, NK = 576, MR = 39, NKT = 36, KCH = 12, PAD = 4;
+    constexpr float LOG2E = 1.4426950408889634f;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    bf16_t* Ks = reinterpret_cast<bf16_t*>(smem);                 // [576][24]
+    bf16_t* Vs = Ks + NK * D;                                     // [576][32]: 24 channels, 1.0, zeros
+    float* tab = reinterpret_cast<float*>(Vs + NK * 32);          // [39*39]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = lane >> 4, c16 = lane & 15;
+    const int wx = blockIdx.x, wy = blockIdx.y;
+    const int b = blockIdx.z / heads, h = blockIdx.z - b * heads;
+    const size_t img = (size_t)b * H * W;
+
+    for (int i = tid; i < MR * MR; i += 256) tab[i] = bias_rot[(size_t)h * MR * MR + i];
+    for (int i = tid; i < NK * 4; i += 256) {
+        const int key = i >> 2, c = i & 3;
+        const int kh = key / WSE, kw = key - kh * WSE;
+        const int y = wy * WS - PAD + kh, x = wx * WS - PAD + kw;
+        const bool inb = y >= 0 && y < H && x >= 0 && x < W;
+        const int vsw = (key >> 1) & 2;  // rows 4..7 of every 8 swap their 32-byte halves: transposed reads stay conflict-free
+        if (c < 3) {
+            u32x4 kq = {0u, 0u, 0u, 0u}, vq = {0u, 0u, 0u, 0u};
+            if (inb) {
+                const bf16_t* p = kv + (img + (size_t)y * W + x) * ldkv + h * D + 8 * c;
+                kq = *reinterpret_cast<const u32x4*>(p);
+                vq = *reinterpret_cast<const u32x4*>(p + C);
+            }
+            *reinterpret_cast<u32x4*>(Ks + key * D + 8 * c) = kq;
+            *reinterpret_cast<u32x4*>(Vs + key * 32 + 8 * (c ^ vsw)) = vq;
+        } else {
+            // channel 24 = 1.0 for EVERY key (out-of-image keys still count in the softmax denominator)
+            *reinterpret_cast<u32x4*>(Vs + key * 32 + 8 * (3 ^ vsw)) = u32x4{0x00003F80u, 0u, 0u, 0u};
+        }
+    }
+    __syncthreads();
+
+    const int trq = c16 >> 2, trp = c16 & 3;  // this lane's address role inside its 16-lane transpose group
+    for (int qt = wave; qt < (WS * WS) / 16; qt += 4) {
+        const int qi = qt * 16 + c16;
+        const int qy = qi >> 4, qx = qi & 15;
+        const size_t qpix = img + (size_t)(wy * WS + qy) * W + (wx * WS + qx);
+        frag_t qf = M::zero();
+        if (g < 3) qf = M::load(q + qpix * ldq + h * D + 8 * g);
+        const bf16_t* krow = Ks + c16 * D + (g < 3 ? 8 * g : 16);   // lanes g == 3 meet a zero Q fragment
+        f32x4 o[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
+        float mrun = -3.0e38f;
+        int kh = (4 * g) / WSE, kw = 4 * g - kh * WSE;
+#pragma unroll 1
+        for (int ch = 0; ch < NKT / KCH; ++ch) {
+            const int kt0 = ch * KCH;
+            f32x4 s[KCH];
+#pragma unroll
+            for (int t = 0; t < KCH; ++t) {
+                const float* tb = tab + (kh - qy + WS - 1) * MR + (kw - qx + WS - 1);
+                const f32x4 bias4 = {tb[0], tb[1], tb[2], tb[3]};
+                const frag_t kf = M::load(krow + (kt0 + t) * 16 * D);
+                s[t] = M::mma(kf, qf, bias4);
+                kw += 16;
+                if (kw >= WSE) { kw -= WSE; ++kh; }
+            }
+            float mx = -3.0e38f;
+#pragma unroll
+            for (int t = 0; t < KCH; ++t) mx = fmaxf(fmaxf(mx, fmaxf(s[t][0], s[t][1])), fmaxf(s[t][2], s[t][3]));
+            mx = fmaxf(mx, __shfl_xor(mx, 16));
+            mx = fmaxf(mx, __shfl_xor(mx, 32));
+            const float mnew = fmaxf(mrun, mx);
+            const float alpha = exp2f((mrun - mnew) * LOG2E);
+            mrun = mnew;
+            const float c2 = -mnew * LOG2E;
+            o[0] *= alpha;
+            o[1] *= alpha;
+#pragma unroll
+            for (int kk = 0; kk < KCH / 2; ++kk) {
+                frag_t pf;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    pf[j] = (bf16_t)exp2f(fmaf(s[2 * kk][j], LOG2E, c2));
+                    pf[4 + j] = (bf16_t)exp2f(fmaf(s[2 * kk + 1][j], LOG2E, c2));
+                }
+                const int key0 = (kt0 + 2 * kk) * 16 + 4 * g;
+#pragma unroll
+                for (int ct = 0; ct < 2; ++ct) {
+                    typedef short s16x4 __attribute__((ext_vector_type(4)));
+                    typedef s16x4 __attribute__((address_space(3))) * lds_s16x4_p;
+                    const bf16_t* va = Vs + (key0 + trq) * 32 + (ct ^ (g & 1)) * 16 + 4 * trp;
+                    const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_p)(va));
+                    const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_p)(va + 16 * 32));
+                    typedef short s16x8 __attribute__((ext_vector_type(8)));
+                    const s16x8 both = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+                    o[ct] = M::mma(__builtin_bit_cast(frag_t, both), pf, o[ct]);
+                }
+            }
+        }
+        // row 24 of O^T is the softmax denominator: lane (c16, g = 2), register o[1][0]
+        const float l = __shfl(o[1][0], 32 + c16);
+        const float inv = 1.0f / l;
+        bf16_t* op = out + qpix * ldo + h * D + 4 * g;
+        Vec4<bf16_t>::store(op, o[0] * inv);
+        if (g < 2) Vec4<bf16_t>::store(op + 16, o[1] * inv);
+    }
+}
+
 template <typename T, int NKT, int KCH>
 int launch_attn(const void* q, const void* kv, const float* bias_rot, void* out, int B, int H, int W, int C, int heads,
                 int ws, int wse, int ldq, int ldkv, int ldo, hipStream_t s) {
@@ -193,6 +308,15 @@ extern "C" int hat_ocab_attention(const void* q, const void* kv, const float* bi
     const int d = C / heads;
     if (d > 32 || d % 2 || ldq < C || ldkv < 2 * C || ldo < C) return HAT_EINVAL;
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    if (dtype == HAT_BF16 && d == 24 && ws == 16 && wse == 24 && ldq % 8 == 0 && ldkv % 8 == 0 && ldo % 4 == 0 && C % 8 == 0) {
+        const size_t lds = (size_t)576 * 24 * 2 + (size_t)576 * 32 * 2 + (size_t)39 * 39 * 4;
+        auto kern = ocab_attn_fast_kernel;
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return (int)e;
+        HAT_LAUNCH(kern, dim3(W / ws, H / ws, B * heads), dim3(256), lds, s, reinterpret_cast<const bf16_t*>(q),
+                   reinterpret_cast<const bf16_t*>(kv), bias_rot, reinterpret_cast<bf16_t*>(out), H, W, C, heads, ldq, ldkv, ldo);
+        return hat_check_launch();
+    }
     const int nkt = wse * wse / 16;
 #define HAT_ATTN_CASE(TT, N, K) return launch_attn<TT, N, K>(q, kv, bias_rot, out, B, H, W, C, heads, ws, wse, ldq, ldkv, ldo, s)
     if (dtype == HAT_BF16) {
