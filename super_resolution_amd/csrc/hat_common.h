@@ -109,7 +109,7 @@ template <> struct Vec4<bf16_t> {
 // LDS row stride (in elements) for rows of `n` elements of size `es`: a multiple of 16 bytes with
 // an ODD number of 16-byte slots, so 16 consecutive rows read at one k offset by ds_read_b128
 // spread over all 64 banks (cdna guide §2 / Guideline 4).
-__host__ __device__ inline int lds_row_elems(int n, int es) {
+__host__ __device__ constexpr int lds_row_elems(int n, int es) {
     int slots = (n * es + 15) / 16;
     if ((slots & 1) == 0) slots += 1;
     return slots * 16 / es;

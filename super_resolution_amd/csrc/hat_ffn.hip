@@ -48,7 +48,7 @@ template <typename T, bool MSWZ> __host__ __device__ inline int ffn_ldm(int C) {
 template <typename T, int WAVES, bool MSWZ>
 __host__ __device__ inline size_t ffn_lds_bytes(int C) {
     const int nph = (2 * WAVES + 2) * HALO_W;
-    const size_t ms = (size_t)nph * ffn_ldm<T, MSWZ>(C) * sizeof(T);
+    const size_t ms = ((size_t)nph * ffn_ldm<T, MSWZ>(C) * sizeof(T) + 255) & ~(size_t)255;  // Us starts 256-byte aligned
     const size_t us = (size_t)(nph + 1) * 2 * CH * sizeof(T);  // + the constant-one row (depthwise bias)
     return ms + us;
 }
@@ -59,8 +59,9 @@ __device__ __forceinline__ float silu_exact(float x) { return x / (1.0f + expf(-
 // DBG is a timing-ablation mask used only by tools/ubench_ffn.hip (the library instantiates DBG = 0):
 //   1 skip LN stage, 2 skip fc1 MFMA loop, 4 skip the dw MFMAs, 8 skip gate math, 16 skip fc2 MFMAs,
 //   32 skip all weight-fragment loads
-template <typename T, int WAVES, int NT, int KS, bool MSWZ, int DBG = 0>
-__global__ __launch_bounds__(WAVES * 64) void ffn_kernel(const HatFfnDesc d) {
+// MINW = waves per SIMD the register allocation must allow (2 when two workgroups' LDS fit one CU)
+template <typename T, int WAVES, int NT, int KS, bool MSWZ, int MINW, int DBG = 0>
+__global__ __launch_bounds__(WAVES * 64, MINW) void ffn_kernel(const HatFfnDesc d) {
     using M = MT<T>;
     using frag_t = typename M::frag_t;
     constexpr int NTHR = WAVES * 64;
@@ -75,12 +76,12 @@ __global__ __launch_bounds__(WAVES * 64) void ffn_kernel(const HatFfnDesc d) {
 
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int C = d.C;
-    const int Kp = ffn_kp(C);
-    const int ldm = ffn_ldm<T, MSWZ>(C);
+    constexpr int Kp = KS * 32;                   // == ffn_kp(C): checked by the launcher
+    constexpr int ldm = MSWZ ? Kp : lds_row_elems(Kp, sizeof(T));
     // 16-byte slot -> element offset inside an Ms row (swizzled when MSWZ: rows of 4 (mod 8) slots collide 4 apart)
     auto ms_slot = [](int row, int slot) { return (MSWZ ? (slot ^ ((row >> 2) & 3)) : slot) * VECN; };
     T* Ms = reinterpret_cast<T*>(smem);
-    T* Us = Ms + (size_t)NPH * ldm;
+    T* Us = reinterpret_cast<T*>(smem + (((size_t)NPH * ldm * sizeof(T) + 255) & ~(size_t)255));  // 256-byte aligned: see uoff
 
     const int tid = threadIdx.x, lane = tid & 63, g = lane >> 4, c16 = lane & 15;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -175,45 +176,62 @@ __global__ __launch_bounds__(WAVES * 64) void ffn_kernel(const HatFfnDesc d) {
             for (int ks = 0; ks < KS; ++ks)
                 a1[i][ks] = (DBG & 32) ? M::zero() : M::load(w1f + ((((size_t)chunk * 4 + (2 * nt2 + i)) * KS + ks) * 64 + lane) * 8);
     };
-    // B operand of fc1: the LayerNorm'ed pixels of one 16-pixel tile, all K
-    auto load_b = [&](int pt, frag_t (&bf)[KS]) {
-        int hpc = pt * 16 + c16;
-        hpc = hpc < NPH ? hpc : NPH - 1;
-        const T* mrow = Ms + (size_t)hpc * ldm;
+    // B operand of fc1: the LayerNorm'ed pixels of one 16-pixel tile, all K.  A wave's tiles are PG * 16 rows
+    // apart, which leaves both swizzles unchanged, so every read/write of phase A is ONE per-lane base plus a
+    // compile-time offset.  Tiles may run past NPH (into Us): those columns are never stored.
+    const int hpa = pg * 16 + c16;
+    const T* mbase = Ms + (size_t)hpa * ldm + ms_slot(hpa, BF ? g : 2 * g);
+    auto load_b = [&](int i, frag_t (&bf)[KS]) {
+        const T* mrow = mbase + (size_t)i * (PG * 16 * ldm);
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks) {
             if constexpr (BF) {
-                bf[ks] = M::load(mrow + ms_slot(hpc, 4 * ks + g));
+                bf[ks] = M::load(mrow + ks * 32);
             } else {
-                const f32x4 lo = *reinterpret_cast<const f32x4*>(mrow + ms_slot(hpc, 8 * ks + 2 * g));
-                const f32x4 hi = *reinterpret_cast<const f32x4*>(mrow + ms_slot(hpc, 8 * ks + 2 * g + 1));
+                const f32x4 lo = *reinterpret_cast<const f32x4*>(mrow + ks * 32);
+                const f32x4 hi = *reinterpret_cast<const f32x4*>(mrow + ks * 32 + 4);
                 bf[ks][0] = lo[0]; bf[ks][1] = lo[1]; bf[ks][2] = lo[2]; bf[ks][3] = lo[3];
                 bf[ks][4] = hi[0]; bf[ks][5] = hi[1]; bf[ks][6] = hi[2]; bf[ks][7] = hi[3];
             }
         }
     };
-    // B operands of the depthwise stage for tap pair `pr`: [group][row] fragments of the shifted pixels.
-    // Lanes g >= 2 of pair 4 carry the BIAS "tap": they read the constant-one row NPH of Us.
-    auto load_u = [&](int pr, frag_t (&bf)[4][2]) {
-        const int tapr = 2 * pr + (g >> 1);
-        const int tap = tapr < 9 ? tapr : 8;
-        const int dy = (tap * 11) >> 5, dx = tap - 3 * dy;
-        const int hp0 = (2 * wave + dy) * HALO_W + c16 + dx;   // row 0 of this wave; row 1 is one halo row below
+    // this lane's two Us store positions (n-tiles 2*nt2, 2*nt2+1) for its first tile
+    T* ust[2];
 #pragma unroll
-        for (int pt = 0; pt < 2; ++pt) {
-            const int hp = tapr < 9 ? hp0 + pt * HALO_W : NPH;
-            const T* urow = Us + (size_t)hp * 2 * CH;
+    for (int ii = 0; ii < 2; ++ii) {
+        const int nl = (2 * nt2 + ii) * 16 + 4 * g;  // chunk-local channel: [0,32) a-part, [32,64) gate
+        ust[ii] = Us + (size_t)hpa * 2 * CH + swz_slot<NSU>(hpa, nl / VECN) * VECN + (nl % VECN);
+    }
+    // Depthwise B operands (the shifted pixels' 16 channels, read from Us).  Lanes g < 2 carry tap 2*pr, lanes
+    // g >= 2 tap 2*pr + 1; lanes g >= 2 of pair 4 carry the BIAS "tap" and read the constant-one row NPH.
+    // uoff[pr][row] = LDS byte address of this lane's group-0 fragment; the Us rows are ROWB (a power of two)
+    // bytes and Us is ROWB-aligned, so group gi's fragment is at uoff ^ (gi * ROWB / 4): one v_xor per read,
+    // and the ten addresses are chunk-invariant.
+    constexpr unsigned ROWB = 2 * CH * sizeof(T);
+    unsigned uoff[NPAIR][2];
+    {
+        const unsigned usb = (unsigned)(uintptr_t)(__attribute__((address_space(3))) char*)(char*)Us;
 #pragma unroll
-            for (int gi = 0; gi < 4; ++gi) {
-                if constexpr (BF) {
-                    bf[gi][pt] = M::load(urow + swz_slot<NSU>(hp, 2 * gi + (g & 1)) * VECN);
-                } else {
-                    const f32x4 lo = *reinterpret_cast<const f32x4*>(urow + swz_slot<NSU>(hp, 4 * gi + 2 * (g & 1)) * VECN);
-                    const f32x4 hi = *reinterpret_cast<const f32x4*>(urow + swz_slot<NSU>(hp, 4 * gi + 2 * (g & 1) + 1) * VECN);
-                    bf[gi][pt][0] = lo[0]; bf[gi][pt][1] = lo[1]; bf[gi][pt][2] = lo[2]; bf[gi][pt][3] = lo[3];
-                    bf[gi][pt][4] = hi[0]; bf[gi][pt][5] = hi[1]; bf[gi][pt][6] = hi[2]; bf[gi][pt][7] = hi[3];
-                }
+        for (int pr = 0; pr < NPAIR; ++pr) {
+            const int tapr = 2 * pr + (g >> 1);
+            const int tap = tapr < 9 ? tapr : 8;
+            const int dy = (tap * 11) >> 5, dx = tap - 3 * dy;
+            const int hp0 = (2 * wave + dy) * HALO_W + c16 + dx;   // row 0 of this wave; row 1 is one halo row below
+#pragma unroll
+            for (int pt = 0; pt < 2; ++pt) {
+                const int hp = tapr < 9 ? hp0 + pt * HALO_W : NPH;
+                uoff[pr][pt] = usb + (unsigned)hp * ROWB + (unsigned)swz_slot<NSU>(hp, (BF ? 1 : 2) * (g & 1)) * 16u;
             }
+        }
+    }
+    auto ldu = [&](int pr, int pt, int gi) -> frag_t {
+        const unsigned a = uoff[pr][pt] ^ ((unsigned)gi * (ROWB / 4));
+        if constexpr (BF) {
+            return *(__attribute__((address_space(3))) const frag_t*)(uintptr_t)(a);
+        } else {
+            const f32x4 lo = *(__attribute__((address_space(3))) const f32x4*)(uintptr_t)(a);
+            const f32x4 hi = *(__attribute__((address_space(3))) const f32x4*)(uintptr_t)(a ^ 16u);
+            return frag_t{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
         }
     };
     constexpr int NPTW = (NPT + PG - 1) / PG;  // fc1 pixel tiles per wave
@@ -238,25 +256,21 @@ __global__ __launch_bounds__(WAVES * 64) void ffn_kernel(const HatFfnDesc d) {
         }
         {
             frag_t bcur[KS], bnxt[KS];
-            load_b(pg, bcur);
+            load_b(0, bcur);
 #pragma unroll
             for (int i = 0; i < NPTW; ++i) {
-                const int pt = pg + i * PG;
-                if (i + 1 < NPTW) load_b(pt + PG, bnxt);  // next tile's operands are in flight during these MFMAs
+                if (i + 1 < NPTW) load_b(i + 1, bnxt);  // next tile's operands are in flight during these MFMAs
                 f32x4 acc[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
 #pragma unroll
                 for (int ks = 0; ks < ((DBG & 2) ? 0 : KS); ++ks) {
 #pragma unroll
                     for (int ii = 0; ii < 2; ++ii) acc[ii] = M::mma(a1[ii][ks], bcur[ks], acc[ii]);
                 }
-                const int hp = pt * 16 + c16;
-                if (hp < NPH) {  // also false for the padding tiles pt >= NPT
+                // every tile of every wave is whole except possibly the last ones
+                const bool whole = ((i + 1) * PG * 16) <= NPH;
+                if (whole || hpa + i * PG * 16 < NPH) {
 #pragma unroll
-                    for (int ii = 0; ii < 2; ++ii) {
-                        const int nl = (2 * nt2 + ii) * 16 + 4 * g;  // chunk-local channel: [0,32) a-part, [32,64) gate
-                        const int slot = swz_slot<NSU>(hp, nl / VECN);
-                        Vec4<T>::store(Us + (size_t)hp * 2 * CH + slot * VECN + (nl % VECN), acc[ii]);
-                    }
+                    for (int ii = 0; ii < 2; ++ii) Vec4<T>::store(ust[ii] + (size_t)i * (PG * 16 * 2 * CH), acc[ii]);
                 }
                 if (i + 1 < NPTW) {
 #pragma unroll
@@ -270,44 +284,39 @@ __global__ __launch_bounds__(WAVES * 64) void ffn_kernel(const HatFfnDesc d) {
         f32x4 dacc[4][2];
 #pragma unroll
         for (int gi = 0; gi < 4; ++gi) { dacc[gi][0] = f32x4{0.f, 0.f, 0.f, 0.f}; dacc[gi][1] = dacc[gi][0]; }
-        frag_t a2[NT];
-        {
-            frag_t bc[4][2], bn[4][2];
-            if constexpr (!(DBG & 4)) load_u(0, bc);
+        frag_t a2[NT];  // fc2 weights: issued now, consumed after the gate math
 #pragma unroll
-            for (int pr = 0; pr < NPAIR; ++pr) {
-                if constexpr (!(DBG & 4)) {
-                    if (pr + 1 < NPAIR) load_u(pr + 1, bn);
+        for (int nt = 0; nt < NT; ++nt)
+            a2[nt] = (DBG & 32) ? M::zero() : M::load(w2f + (((size_t)chunk * NT + nt) * 64 + lane) * 8);
+        if constexpr (!(DBG & 4)) {
+            // 20 steps (tap pair, channel group), two MFMAs each (the wave's two rows); operands two steps ahead
+            constexpr int NSTEP = NPAIR * 4, DEPTH = 3;
+            frag_t ub[DEPTH][2];
+            auto issue = [&](int st) {
+                ub[st % DEPTH][0] = ldu(st >> 2, 0, st & 3);
+                ub[st % DEPTH][1] = ldu(st >> 2, 1, st & 3);
+            };
+            issue(0);
+            issue(1);
+#pragma unroll
+            for (int st = 0; st < NSTEP; ++st) {
+                if (st + 2 < NSTEP) issue(st + 2);
+                const int pr = st >> 2, gi = st & 3;
+                // A = [diag(w_tap0) | diag(w_tap1)]: this lane's row (channel c16 of the group) has ONE non-zero
+                // element, at position jstar of its 8-wide k group (the host zeroes the weight in lanes whose k
+                // group does not hold channel c16)
+                frag_t af;
+                if constexpr (BF) {
+                    u32x4 aw;
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) aw[i] = wdw[gi * NPAIR + pr] & dmask[i];
+                    af = __builtin_bit_cast(frag_t, aw);
+                } else {
+#pragma unroll
+                    for (int jj = 0; jj < 8; ++jj) af[jj] = (jj == jstar) ? wdw[gi * NPAIR + pr] : 0.f;
                 }
-                if (pr == NPAIR - 1) {  // fc2 weights: issued now, consumed after the gate math
-#pragma unroll
-                    for (int nt = 0; nt < NT; ++nt)
-                        a2[nt] = (DBG & 32) ? M::zero() : M::load(w2f + (((size_t)chunk * NT + nt) * 64 + lane) * 8);
-                }
-                if constexpr (!(DBG & 4)) {
-#pragma unroll
-                    for (int gi = 0; gi < 4; ++gi) {
-                        // A = [diag(w_tap0) | diag(w_tap1)]: this lane's row (channel c16 of the group) has ONE non-zero
-                        // element, at position jstar of its 8-wide k group (the host zeroes the weight in lanes whose k
-                        // group does not hold channel c16)
-                        frag_t af;
-                        if constexpr (BF) {
-                            u32x4 aw;
-#pragma unroll
-                            for (int i = 0; i < 4; ++i) aw[i] = wdw[gi * NPAIR + pr] & dmask[i];
-                            af = __builtin_bit_cast(frag_t, aw);
-                        } else {
-#pragma unroll
-                            for (int jj = 0; jj < 8; ++jj) af[jj] = (jj == jstar) ? wdw[gi * NPAIR + pr] : 0.f;
-                        }
-                        dacc[gi][0] = M::mma(af, bc[gi][0], dacc[gi][0]);
-                        dacc[gi][1] = M::mma(af, bc[gi][1], dacc[gi][1]);
-                    }
-                    if (pr + 1 < NPAIR) {
-#pragma unroll
-                        for (int gi = 0; gi < 4; ++gi) { bc[gi][0] = bn[gi][0]; bc[gi][1] = bn[gi][1]; }
-                    }
-                }
+                dacc[gi][0] = M::mma(af, ub[st % DEPTH][0], dacc[gi][0]);
+                dacc[gi][1] = M::mma(af, ub[st % DEPTH][1], dacc[gi][1]);
             }
         }
         // ================================ phase C: gate + fc2 ===================================
@@ -422,11 +431,12 @@ __global__ __launch_bounds__(WAVES * 64) void ffn_kernel(const HatFfnDesc d) {
     }
 }
 
-template <typename T, int WAVES, int NT, int KS, bool MSWZ>
+template <typename T, int WAVES, int NT, int KS, bool MSWZ, int MINW>
 int launch_ffn(const HatFfnDesc& d, hipStream_t s) {
+    if (ffn_kp(d.C) != KS * 32 || (d.C + 15) / 16 != NT) return HAT_EUNSUPPORTED;
     const size_t lds = ffn_lds_bytes<T, WAVES, MSWZ>(d.C);
     if (lds > HAT_LDS_MAX) return HAT_ELDS;
-    auto kern = ffn_kernel<T, WAVES, NT, KS, MSWZ>;
+    auto kern = ffn_kernel<T, WAVES, NT, KS, MSWZ, MINW>;
     if (lds > 65536) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return (int)e;
@@ -464,13 +474,13 @@ extern "C" int hat_ffn(const HatFfnDesc* dp, void* stream) {
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     const bool small = d.C <= 32 && d.C % 32 != 16;
     if (d.dtype == HAT_BF16) {
-        if (d.C == 144) return launch_ffn<bf16_t, 4, 9, 5, true>(d, s);
-        if (d.C == 180) return launch_ffn<bf16_t, 4, 12, 6, false>(d, s);
-        if (small) return launch_ffn<bf16_t, 4, 2, 1, true>(d, s);
+        if (d.C == 144) return launch_ffn<bf16_t, 4, 9, 5, true, 2>(d, s);
+        if (d.C == 180) return launch_ffn<bf16_t, 4, 12, 6, false, 1>(d, s);
+        if (small) return launch_ffn<bf16_t, 4, 2, 1, true, 2>(d, s);
     } else if (d.dtype == HAT_F32) {
-        if (d.C == 144) return launch_ffn<float, 2, 9, 5, false>(d, s);
-        if (d.C == 180) return launch_ffn<float, 2, 12, 6, false>(d, s);
-        if (small) return launch_ffn<float, 2, 2, 1, false>(d, s);
+        if (d.C == 144) return launch_ffn<float, 2, 9, 5, false, 1>(d, s);
+        if (d.C == 180) return launch_ffn<float, 2, 12, 6, false, 1>(d, s);
+        if (small) return launch_ffn<float, 2, 2, 1, false, 1>(d, s);
     } else {
         return HAT_EINVAL;
     }

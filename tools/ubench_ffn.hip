@@ -11,7 +11,7 @@ __global__ void fill(float* p, size_t n, float s) { size_t i = blockIdx.x * (siz
 __global__ void fillh(bf16_t* p, size_t n, float s) { size_t i = blockIdx.x * (size_t)256 + threadIdx.x; if (i < n) p[i] = (bf16_t)(s * (float)((i * 2654435761u) % 1000) / 1000.f - 0.5f * s); }
 
 template <int WV, int DBG> float run(const HatFfnDesc& d, int iters) {
-    auto kern = ffn_kernel<bf16_t, WV, 9, 5, true, DBG>;
+    auto kern = ffn_kernel<bf16_t, WV, 9, 5, true, (WV == 4 ? 2 : 1), DBG>;
     const size_t lds = ffn_lds_bytes<bf16_t, WV, true>(d.C);
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     dim3 grid((d.W + 15) / 16, (d.H + 2 * WV - 1) / (2 * WV), d.B);
