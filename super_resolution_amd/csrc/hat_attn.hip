@@ -173,6 +173,13 @@ __global__ __launch_bounds__(256) void ocab_attn_kernel(const T* __restrict__ q,
 //   * the relative-position bias enters as the C operand of the S MFMA: no VALU bias adds;
 //   * p = exp2(fma(s, log2e, -m*log2e)): one FMA + one exp per score.
 // ---------------------------------------------------------------------------------------------------------
+// v_max3_f32 without the per-input canonicalising v_max the compiler adds for fmaxf (scores are never NaN-signalling)
+__device__ __forceinline__ float max3_raw(float a, float b, float c) {
+    float r;
+    asm("v_max3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+    return r;
+}
+
 __global__ __launch_bounds__(256, 2) void ocab_attn_fast_kernel(const bf16_t* __restrict__ q, const bf16_t* __restrict__ kv,
                                                                 const float* __restrict__ bias_rot, bf16_t* __restrict__ out,
                                                                 int H, int W, int C, int heads, int ldq, int ldkv, int ldo) {
@@ -189,60 +196,93 @@ __global__ __launch_bounds__(256, 2) void ocab_attn_fast_kernel(const bf16_t* __
     const int b = blockIdx.z / heads, h = blockIdx.z - b * heads;
     const size_t img = (size_t)b * H * W;
 
-    for (int i = tid; i < MR * MR; i += 256) tab[i] = bias_rot[(size_t)h * MR * MR + i];
-    for (int i = tid; i < NK * 4; i += 256) {
+    // Every global load of the staging phase is issued before the first LDS store (branch-free: out-of-image keys
+    // load a clamped pixel and are zeroed by a select), so the phase costs one memory latency, not nine.
+    frag_t qfr[4];   // this wave's four query tiles: query tile qt = window row qt, lane c16 = window column
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const size_t qpix = img + (size_t)(wy * WS + wave + 4 * i) * W + (wx * WS + c16);
+        qfr[i] = M::load(q + qpix * ldq + h * D + 8 * (g < 3 ? g : 2));
+        if (g == 3) qfr[i] = M::zero();
+    }
+    constexpr int NTAB = (MR * MR + 255) / 256, NIT = NK * 4 / 256;
+    float tv[NTAB];
+#pragma unroll
+    for (int it = 0; it < NTAB; ++it) {
+        const int i = tid + it * 256;
+        tv[it] = bias_rot[(size_t)h * MR * MR + (i < MR * MR ? i : MR * MR - 1)];
+    }
+    u32x4 kq[NIT], vq[NIT];
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) {
+        const int i = tid + it * 256;
+        const int key = i >> 2, c = i & 3;
+        const int kh = key / WSE, kw = key - kh * WSE;
+        const int y = wy * WS - PAD + kh, x = wx * WS - PAD + kw;
+        const int yc = min(max(y, 0), H - 1), xc = min(max(x, 0), W - 1);
+        const bf16_t* p = kv + (img + (size_t)yc * W + xc) * ldkv + h * D + 8 * (c < 3 ? c : 2);
+        kq[it] = *reinterpret_cast<const u32x4*>(p);
+        vq[it] = *reinterpret_cast<const u32x4*>(p + C);
+    }
+#pragma unroll
+    for (int it = 0; it < NTAB; ++it) {
+        const int i = tid + it * 256;
+        if (i < MR * MR) tab[i] = tv[it];
+    }
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) {
+        const int i = tid + it * 256;
         const int key = i >> 2, c = i & 3;
         const int kh = key / WSE, kw = key - kh * WSE;
         const int y = wy * WS - PAD + kh, x = wx * WS - PAD + kw;
         const bool inb = y >= 0 && y < H && x >= 0 && x < W;
         const int vsw = (key >> 1) & 2;  // rows 4..7 of every 8 swap their 32-byte halves: transposed reads stay conflict-free
-        if (c < 3) {
-            u32x4 kq = {0u, 0u, 0u, 0u}, vq = {0u, 0u, 0u, 0u};
-            if (inb) {
-                const bf16_t* p = kv + (img + (size_t)y * W + x) * ldkv + h * D + 8 * c;
-                kq = *reinterpret_cast<const u32x4*>(p);
-                vq = *reinterpret_cast<const u32x4*>(p + C);
-            }
-            *reinterpret_cast<u32x4*>(Ks + key * D + 8 * c) = kq;
-            *reinterpret_cast<u32x4*>(Vs + key * 32 + 8 * (c ^ vsw)) = vq;
-        } else {
-            // channel 24 = 1.0 for EVERY key (out-of-image keys still count in the softmax denominator)
-            *reinterpret_cast<u32x4*>(Vs + key * 32 + 8 * (3 ^ vsw)) = u32x4{0x00003F80u, 0u, 0u, 0u};
-        }
+        const u32x4 zero = {0u, 0u, 0u, 0u};
+        // channel 24 = 1.0 for EVERY key (out-of-image keys still count in the softmax denominator)
+        const u32x4 vval = c == 3 ? u32x4{0x00003F80u, 0u, 0u, 0u} : (inb ? vq[it] : zero);
+        *reinterpret_cast<u32x4*>(Vs + key * 32 + 8 * (c ^ vsw)) = vval;
+        if (c < 3) *reinterpret_cast<u32x4*>(Ks + key * D + 8 * c) = inb ? kq[it] : zero;
     }
     __syncthreads();
 
     const int trq = c16 >> 2, trp = c16 & 3;  // this lane's address role inside its 16-lane transpose group
-    for (int qt = wave; qt < (WS * WS) / 16; qt += 4) {
-        const int qi = qt * 16 + c16;
-        const int qy = qi >> 4, qx = qi & 15;
-        const size_t qpix = img + (size_t)(wy * WS + qy) * W + (wx * WS + qx);
-        frag_t qf = M::zero();
-        if (g < 3) qf = M::load(q + qpix * ldq + h * D + 8 * g);
+    // Bias-table offsets of this lane's 4 keys (rows 4g..4g+3 of key tile t; 24 % 4 == 0 keeps them in one key
+    // row) against query column c16 of window row 0.  A chunk of 12 key tiles is exactly 8 key rows and a query
+    // tile is exactly one window row, so chunk ch / query tile qt only add the uniform (8 * ch - qt) * MR.
+    int toff[KCH];
+#pragma unroll
+    for (int t = 0; t < KCH; ++t) {
+        const int key = t * 16 + 4 * g;
+        const int kh = key / WSE, kw = key - kh * WSE;
+        toff[t] = (kh + WS - 1) * MR + (kw - c16 + WS - 1);
+    }
+#pragma unroll
+    for (int qi4 = 0; qi4 < 4; ++qi4) {
+        const int qt = wave + 4 * qi4;
+        const size_t qpix = img + (size_t)(wy * WS + qt) * W + (wx * WS + c16);
+        const frag_t qf = qfr[qi4];
         const bf16_t* krow = Ks + c16 * D + (g < 3 ? 8 * g : 16);   // lanes g == 3 meet a zero Q fragment
         f32x4 o[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
         float mrun = -3.0e38f;
-        int kh = (4 * g) / WSE, kw = 4 * g - kh * WSE;
 #pragma unroll 1
         for (int ch = 0; ch < NKT / KCH; ++ch) {
             const int kt0 = ch * KCH;
+            const float* tbase = tab + (8 * ch - qt) * MR;
             f32x4 s[KCH];
 #pragma unroll
             for (int t = 0; t < KCH; ++t) {
-                const float* tb = tab + (kh - qy + WS - 1) * MR + (kw - qx + WS - 1);
+                const float* tb = tbase + toff[t];
                 const f32x4 bias4 = {tb[0], tb[1], tb[2], tb[3]};
                 const frag_t kf = M::load(krow + (kt0 + t) * 16 * D);
                 s[t] = M::mma(kf, qf, bias4);
-                kw += 16;
-                if (kw >= WSE) { kw -= WSE; ++kh; }
             }
             float mx = -3.0e38f;
 #pragma unroll
-            for (int t = 0; t < KCH; ++t) mx = fmaxf(fmaxf(mx, fmaxf(s[t][0], s[t][1])), fmaxf(s[t][2], s[t][3]));
+            for (int t = 0; t < KCH; ++t) mx = max3_raw(max3_raw(mx, s[t][0], s[t][1]), s[t][2], s[t][3]);
             mx = fmaxf(mx, __shfl_xor(mx, 16));
             mx = fmaxf(mx, __shfl_xor(mx, 32));
             const float mnew = fmaxf(mrun, mx);
-            const float alpha = exp2f((mrun - mnew) * LOG2E);
+            const float alpha = __builtin_amdgcn_exp2f((mrun - mnew) * LOG2E);  // raw v_exp_f32: underflow flushes to 0
             mrun = mnew;
             const float c2 = -mnew * LOG2E;
             o[0] *= alpha;
@@ -252,8 +292,8 @@ __global__ __launch_bounds__(256, 2) void ocab_attn_fast_kernel(const bf16_t* __
                 frag_t pf;
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
-                    pf[j] = (bf16_t)exp2f(fmaf(s[2 * kk][j], LOG2E, c2));
-                    pf[4 + j] = (bf16_t)exp2f(fmaf(s[2 * kk + 1][j], LOG2E, c2));
+                    pf[j] = (bf16_t)__builtin_amdgcn_exp2f(fmaf(s[2 * kk][j], LOG2E, c2));
+                    pf[4 + j] = (bf16_t)__builtin_amdgcn_exp2f(fmaf(s[2 * kk + 1][j], LOG2E, c2));
                 }
                 const int key0 = (kt0 + 2 * kk) * 16 + 4 * g;
 #pragma unroll
