@@ -72,7 +72,9 @@ __global__ __launch_bounds__(WAVES * 64, MINW) void ffn_kernel(const HatFfnDesc 
     constexpr int NSU = 2 * CH / VECN;            // 16-byte slots per Us row
     constexpr int PG = WAVES / 2;                 // fc1 pixel groups (each handled by 2 waves: n-tile pairs)
     constexpr bool BF = sizeof(T) == 2;
-    constexpr int LNB = 4;                        // pixels per 16-lane group kept in flight in the LN stage
+    // pixels per 16-lane group kept in flight in the LN stage: bf16 takes the whole haloed tile in ONE pass (nothing else
+    // is live yet), because every pass costs a full HBM round trip
+    constexpr int LNB = BF ? (NPH + NTHR / 16 - 1) / (NTHR / 16) : 4;
 
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int C = d.C;
@@ -91,10 +93,20 @@ __global__ __launch_bounds__(WAVES * 64, MINW) void ffn_kernel(const HatFfnDesc 
     const int hid_p = d.chunks * CH;
 
     // ------------------------------ stage 0: LayerNorm2 -> Ms --------------------------------
+    // Every global load here is unconditional (clamped address, result discarded by a select): a load under a lane
+    // mask whose result merges with a default makes the compiler wait for it right where it is issued, which turned
+    // this stage into one memory round trip per load.  gamma/beta are read once, not per pixel.
     if constexpr (!(DBG & 1)) {
         const int j = tid & 15, grp = tid >> 4;
         constexpr int NGRP = NTHR / 16;
         const float invC = 1.0f / (float)C;
+        f32x4 gmv[3], btv[3];
+#pragma unroll
+        for (int v = 0; v < 3; ++v) {
+            const int c = min(4 * j + 64 * v, C - 4);
+            gmv[v] = *reinterpret_cast<const f32x4*>(d.ln_g + c);
+            btv[v] = *reinterpret_cast<const f32x4*>(d.ln_b + c);
+        }
         for (int base = 0; base < NPH; base += NGRP * LNB) {
             f32x4 xv[LNB][3];
             bool inside[LNB];
@@ -104,19 +116,19 @@ __global__ __launch_bounds__(WAVES * 64, MINW) void ffn_kernel(const HatFfnDesc 
                 const int hy = hp / HALO_W, hx = hp - hy * HALO_W;
                 const int y = y0 - 1 + hy, x = x0 - 1 + hx;
                 inside[u] = hp < NPH && y >= 0 && y < H && x >= 0 && x < W;
+                const float* src = tin + ((size_t)min(max(y, 0), H - 1) * W + min(max(x, 0), W - 1)) * C;
 #pragma unroll
-                for (int v = 0; v < 3; ++v) {
-                    const int c = 4 * j + 64 * v;
-                    xv[u][v] = f32x4{0.f, 0.f, 0.f, 0.f};
-                    if (inside[u] && c < C) xv[u][v] = *reinterpret_cast<const f32x4*>(tin + ((size_t)y * W + x) * C + c);
-                }
+                for (int v = 0; v < 3; ++v) xv[u][v] = *reinterpret_cast<const f32x4*>(src + min(4 * j + 64 * v, C - 4));
             }
 #pragma unroll
             for (int u = 0; u < LNB; ++u) {
                 const int hp = base + u * NGRP + grp;
                 float s = 0.f;
 #pragma unroll
-                for (int v = 0; v < 3; ++v) s += (xv[u][v][0] + xv[u][v][1]) + (xv[u][v][2] + xv[u][v][3]);
+                for (int v = 0; v < 3; ++v) {
+                    if (!(inside[u] && 4 * j + 64 * v < C)) xv[u][v] = f32x4{0.f, 0.f, 0.f, 0.f};
+                    s += (xv[u][v][0] + xv[u][v][1]) + (xv[u][v][2] + xv[u][v][3]);
+                }
                 s += __shfl_xor(s, 1); s += __shfl_xor(s, 2); s += __shfl_xor(s, 4); s += __shfl_xor(s, 8);
                 const float mean = s * invC;
                 float q = 0.f;
@@ -136,10 +148,8 @@ __global__ __launch_bounds__(WAVES * 64, MINW) void ffn_kernel(const HatFfnDesc 
                         if (c < Kp) {
                             f32x4 o = {0.f, 0.f, 0.f, 0.f};
                             if (inside[u] && c < C) {
-                                const f32x4 gm = *reinterpret_cast<const f32x4*>(d.ln_g + c);
-                                const f32x4 bt = *reinterpret_cast<const f32x4*>(d.ln_b + c);
 #pragma unroll
-                                for (int r = 0; r < 4; ++r) o[r] = (xv[u][v][r] - mean) * rstd * gm[r] + bt[r];
+                                for (int r = 0; r < 4; ++r) o[r] = (xv[u][v][r] - mean) * rstd * gmv[v][r] + btv[v][r];
                             } else if (inside[u] && c == C) {
                                 o[0] = 1.0f;  // bias column (C % 4 == 0)
                             }
@@ -151,10 +161,19 @@ __global__ __launch_bounds__(WAVES * 64, MINW) void ffn_kernel(const HatFfnDesc 
         }
     }
 
-    // persistent fc2 accumulators: this wave's two tile rows x all NT channel tiles
+    // persistent fc2 accumulators: this wave's two tile rows x all NT channel tiles, initialised with the residual
+    // t_in + b2 (clamped, unconditional loads that complete during chunk 0; out-of-image pixels and pad channels hold
+    // values that are never stored)
     f32x4 acc2[NT][2];
 #pragma unroll
-    for (int nt = 0; nt < NT; ++nt) { acc2[nt][0] = *reinterpret_cast<const f32x4*>(d.b2 + nt * 16 + 4 * (lane >> 4)); acc2[nt][1] = acc2[nt][0]; }
+    for (int pt = 0; pt < 2; ++pt) {
+        const size_t pixc = (size_t)min(y0 + 2 * wave + pt, H - 1) * W + min(x0 + c16, W - 1);
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) {
+            const int n = nt * 16 + 4 * g;
+            acc2[nt][pt] = *reinterpret_cast<const f32x4*>(d.b2 + n) + *reinterpret_cast<const f32x4*>(tin + pixc * C + min(n, C - 4));
+        }
+    }
 
     const T* w1f = reinterpret_cast<const T*>(d.w1f);
     const T* w2f = reinterpret_cast<const T*>(d.w2f);
@@ -366,6 +385,15 @@ __global__ __launch_bounds__(WAVES * 64, MINW) void ffn_kernel(const HatFfnDesc 
     float* tout = d.t_out + (size_t)b * H * W * C;
     const bool do_ln = d.ln1_g != nullptr;
     f32x4 gapv = {0.f, 0.f, 0.f, 0.f};
+    f32x4 g1v[NT], b1v[NT];  // next LayerNorm's gamma/beta for this lane's channels: one batch of loads, not 2 per n-tile
+    if (do_ln) {
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) {
+            const int n = min(nt * 16 + 4 * g, C - 4);
+            g1v[nt] = *reinterpret_cast<const f32x4*>(d.ln1_g + n);
+            b1v[nt] = *reinterpret_cast<const f32x4*>(d.ln1_b + n);
+        }
+    }
 #pragma unroll
     for (int pt = 0; pt < 2; ++pt) {
         const int y = y0 + 2 * wave + pt, x = x0 + c16;
@@ -377,7 +405,7 @@ __global__ __launch_bounds__(WAVES * 64, MINW) void ffn_kernel(const HatFfnDesc 
             const int n = nt * 16 + 4 * g;
             f32x4 v = {0.f, 0.f, 0.f, 0.f};
             if (valid && n < C) {
-                v = acc2[nt][pt] + *reinterpret_cast<const f32x4*>(tin + pix * C + n);
+                v = acc2[nt][pt];
                 *reinterpret_cast<f32x4*>(tout + pix * C + n) = v;
             }
             acc2[nt][pt] = v;
@@ -401,11 +429,9 @@ __global__ __launch_bounds__(WAVES * 64, MINW) void ffn_kernel(const HatFfnDesc 
             for (int nt = 0; nt < NT; ++nt) {
                 const int n = nt * 16 + 4 * g;
                 if (valid && n < C) {
-                    const f32x4 gm = *reinterpret_cast<const f32x4*>(d.ln1_g + n);
-                    const f32x4 bt = *reinterpret_cast<const f32x4*>(d.ln1_b + n);
                     f32x4 o;
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) o[r] = (acc2[nt][pt][r] - mean) * rstd * gm[r] + bt[r];
+                    for (int r = 0; r < 4; ++r) o[r] = (acc2[nt][pt][r] - mean) * rstd * g1v[nt][r] + b1v[nt][r];
                     Vec4<T>::store(nout + n, o);
                     if (nt == 0 && n < d.gap_c) gapv += o;
                 }
