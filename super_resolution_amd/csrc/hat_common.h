@@ -88,11 +88,21 @@ __device__ __forceinline__ float to_f(bf16_t v) { return (float)v; }
 // 4 consecutive T values <-> 4 floats
 template <typename T> struct Vec4;
 template <> struct Vec4<float> {
+    typedef f32x4 raw_t;  // load_raw / cvt split a load from its conversion, so a batch of loads can stay in flight
+    static __device__ __forceinline__ raw_t load_raw(const float* p) { return *reinterpret_cast<const f32x4*>(p); }
+    static __device__ __forceinline__ f32x4 cvt(raw_t r) { return r; }
     static __device__ __forceinline__ f32x4 load(const float* p) { return *reinterpret_cast<const f32x4*>(p); }
     static __device__ __forceinline__ void store(float* p, f32x4 v) { *reinterpret_cast<f32x4*>(p) = v; }
 };
 template <> struct Vec4<bf16_t> {
     typedef bf16_t v4 __attribute__((ext_vector_type(4)));
+    typedef v4 raw_t;
+    static __device__ __forceinline__ raw_t load_raw(const bf16_t* p) { return *reinterpret_cast<const v4*>(p); }
+    static __device__ __forceinline__ f32x4 cvt(raw_t h) {
+        f32x4 r;
+        r[0] = (float)h[0]; r[1] = (float)h[1]; r[2] = (float)h[2]; r[3] = (float)h[3];
+        return r;
+    }
     static __device__ __forceinline__ f32x4 load(const bf16_t* p) {
         const v4 h = *reinterpret_cast<const v4*>(p);
         f32x4 r;

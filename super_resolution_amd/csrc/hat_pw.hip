@@ -16,8 +16,9 @@
 
 namespace {
 
-template <typename T, int NT, int KS, int WAVES, int MINW>
-__global__ __launch_bounds__(WAVES * 64, MINW) void pw_kernel(const HatConvDesc d, long npix_total, int tiles) {
+// RES: the launch has residual operands (r1 and/or r2): their loads are batched ahead of the MFMAs (+54 registers)
+template <typename T, int NT, int KS, int WAVES, int MINW, bool RES>
+__global__ __launch_bounds__(WAVES * 64, MINW) void pw_kernel(const HatConvDesc d, long npix_total, int tiles, int scale_in_lds) {
     using M = MT<T>;
     using frag_t = typename M::frag_t;
     constexpr int KSMAX = KS;
@@ -35,28 +36,46 @@ __global__ __launch_bounds__(WAVES * 64, MINW) void pw_kernel(const HatConvDesc 
     f32x4 bias[NT];
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) bias[nt] = *reinterpret_cast<const f32x4*>(d.bias + nbase + nt * 16 + 4 * g);
+    // r2's per-(batch, channel) scale: a [B][NT*16] table in LDS behind the weights (when the launcher found room)
+    float* sct = reinterpret_cast<float*>(smem + (size_t)NT * KS * 64 * 8 * sizeof(T));
+    if (RES && scale_in_lds) {
+        for (int i = tid; i < d.B * NT * 16; i += nthr) {
+            const int bb = i / (NT * 16), n = nbase + (i - bb * NT * 16);
+            sct[i] = n < d.n_store ? d.r2scale[(size_t)bb * d.r2scale_bstride + n] : 0.f;
+        }
+    }
     __syncthreads();
 
     const T* xg = reinterpret_cast<const T*>(d.x);
     const T* xg0 = reinterpret_cast<const T*>(d.x0);
     const int Cin = d.Cin;
+    // B fragments of one 16-pixel tile.  bf16: every load is unconditional — k groups at or beyond Cin re-read the
+    // row's last 8-channel group (finite activations against zero weight columns) — because a load under a lane mask
+    // that merges with a default is waited for where it is issued, which would make this one-tile-ahead prefetch
+    // synchronous.
     auto load_b = [&](long tile, frag_t (&bf)[KSMAX]) {
         long p = tile * 16 + c16;
         p = p < npix_total ? p : npix_total - 1;
 #pragma unroll
         for (int ks = 0; ks < KSMAX; ++ks) {
             if (ks < ks_total) {
-                const int c = ks * 32 + 8 * g;
-                if (c + 8 <= Cin || (sizeof(T) == 2 && c < Cin)) {  // bf16 rows are padded to a multiple of 8 channels
+                if constexpr (sizeof(T) == 2) {
+                    const int c = min(ks * 32 + 8 * g, ((Cin + 7) & ~7) - 8);
                     const T* src = (xg0 != nullptr && c < d.c_split) ? xg0 + p * d.ldx0 + c : xg + p * d.ldx + c;
                     bf[ks] = M::load(src);
-                } else if (c < Cin) {                                // f32 tail: 4 valid channels
-                    const f32x4 lo = *reinterpret_cast<const f32x4*>(xg + p * d.ldx + c);
-                    frag_t t = M::zero();
-                    t[0] = to_T<T>(lo[0]); t[1] = to_T<T>(lo[1]); t[2] = to_T<T>(lo[2]); t[3] = to_T<T>(lo[3]);
-                    bf[ks] = t;
                 } else {
-                    bf[ks] = M::zero();
+                    const int c = ks * 32 + 8 * g;
+                    if (c + 8 <= Cin) {
+                        const T* src = (xg0 != nullptr && c < d.c_split) ? xg0 + p * d.ldx0 + c : xg + p * d.ldx + c;
+                        bf[ks] = M::load(src);
+                    } else if (c < Cin) {                                // f32 tail: 4 valid channels
+                        const f32x4 lo = *reinterpret_cast<const f32x4*>(xg + p * d.ldx + c);
+                        frag_t t = M::zero();
+                        t[0] = to_T<T>(lo[0]); t[1] = to_T<T>(lo[1]); t[2] = to_T<T>(lo[2]); t[3] = to_T<T>(lo[3]);
+                        bf[ks] = t;
+                    } else {
+                        bf[ks] = M::zero();
+                    }
                 }
             }
         }
@@ -68,6 +87,22 @@ __global__ __launch_bounds__(WAVES * 64, MINW) void pw_kernel(const HatConvDesc 
     if (tile < tiles) load_b(tile, bcur);
     for (; tile < tiles; tile += stride) {
         if (tile + stride < tiles) load_b(tile + stride, bnxt);
+        // Residual operands of THIS tile, all issued before the MFMAs: the compiler must assume `out` aliases r1 / r2,
+        // so loads placed between the stores below are serialised one memory round trip at a time.
+        const long p = tile * 16 + c16;
+        const long pc = p < npix_total ? p : npix_total - 1;
+        const long bidx = pc / ((long)d.H * d.W);
+        const bool has_r1 = RES && d.r1 != nullptr, has_r2 = RES && d.r2 != nullptr;
+        f32x4 r1v[RES ? NT : 1];
+        typename Vec4<T>::raw_t r2v[RES ? NT : 1];
+        if constexpr (RES) {
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) {
+                const int n = min(nbase + nt * 16 + 4 * g, d.n_store - 4);
+                if (has_r1) r1v[nt] = *reinterpret_cast<const f32x4*>(d.r1 + pc * d.ldr1 + n);
+                if (has_r2) r2v[nt] = Vec4<T>::load_raw(reinterpret_cast<const T*>(d.r2) + pc * d.ldr2 + n);
+            }
+        }
         f32x4 acc[NT];
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) acc[nt] = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -85,9 +120,7 @@ __global__ __launch_bounds__(WAVES * 64, MINW) void pw_kernel(const HatConvDesc 
                 }
             }
         }
-        const long p = tile * 16 + c16;
         if (p < npix_total) {
-            const long bidx = p / ((long)d.H * d.W);
 #pragma unroll
             for (int nt = 0; nt < NT; ++nt) {
                 const int n = nbase + nt * 16 + 4 * g;
@@ -100,10 +133,13 @@ __global__ __launch_bounds__(WAVES * 64, MINW) void pw_kernel(const HatConvDesc 
 #pragma unroll
                         for (int r = 0; r < 4; ++r) v[r] = v[r] >= 0.f ? v[r] : 0.01f * v[r];
                     }
-                    if (d.r1 != nullptr) v += *reinterpret_cast<const f32x4*>(d.r1 + p * d.ldr1 + n);
-                    if (d.r2 != nullptr) {
-                        const f32x4 rv = Vec4<T>::load(reinterpret_cast<const T*>(d.r2) + p * d.ldr2 + n);
-                        v += *reinterpret_cast<const f32x4*>(d.r2scale + bidx * d.r2scale_bstride + n) * rv;
+                    if constexpr (RES) {
+                        if (has_r1) v += r1v[nt];
+                        if (has_r2) {
+                            const f32x4 sc = scale_in_lds ? *reinterpret_cast<const f32x4*>(sct + bidx * (NT * 16) + nt * 16 + 4 * g)
+                                                          : *reinterpret_cast<const f32x4*>(d.r2scale + bidx * d.r2scale_bstride + n);
+                            v += sc * Vec4<T>::cvt(r2v[nt]);
+                        }
                     }
                     if (d.out_mode == HAT_O_NHWC_T) Vec4<T>::store(reinterpret_cast<T*>(d.out) + p * d.ldo + n, v);
                     else *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(d.out) + p * d.ldo + n) = v;
@@ -115,35 +151,38 @@ __global__ __launch_bounds__(WAVES * 64, MINW) void pw_kernel(const HatConvDesc 
     }
 }
 
-template <typename T, int NT, int KS>
-int launch_pw(const HatConvDesc& d, hipStream_t s) {
-    const size_t lds = (size_t)NT * KS * 64 * 8 * sizeof(T);  // a fragment is 64 lanes x 8 elements
-    if (lds > HAT_LDS_MAX) return HAT_EUNSUPPORTED;
+template <typename T, int NT, int KS, int WAVES, int MINW, bool RES>
+int launch_pw_cfg(const HatConvDesc& d, hipStream_t s, size_t lds, int wgs_per_cu, int scale_in_lds) {
     const long npix = (long)d.B * d.H * d.W;
     const int tiles = (int)((npix + 15) / 16);
-    int wgs_per_cu = (int)(HAT_LDS_MAX / lds);
-    wgs_per_cu = wgs_per_cu > 3 ? 3 : wgs_per_cu;
-    const bool big = wgs_per_cu < 2;  // one big-LDS workgroup per CU gets 8 waves, otherwise 4 waves x up to 3 workgroups
-    const int waves = big ? 8 : 4;
     int gx = 256 * wgs_per_cu;
-    if (gx > (tiles + waves - 1) / waves) gx = (tiles + waves - 1) / waves;
-    dim3 grid(gx, d.n_slices, 1);
-    // waves per SIMD the register allocation is sized for: 3 workgroups x 4 waves -> 3, 2 x 4 -> 2, 1 x 8 -> 2
-    if (big) {
-        auto kern = pw_kernel<T, NT, KS, 8, 2>;
+    if (gx > (tiles + WAVES - 1) / WAVES) gx = (tiles + WAVES - 1) / WAVES;
+    auto kern = pw_kernel<T, NT, KS, WAVES, MINW, RES>;
+    if (lds > 65536) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return (int)e;
-        HAT_LAUNCH(kern, grid, dim3(512), lds, s, d, npix, tiles);
-    } else if (wgs_per_cu == 2) {
-        auto kern = pw_kernel<T, NT, KS, 4, 2>;
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (e != hipSuccess) return (int)e;
-        HAT_LAUNCH(kern, grid, dim3(256), lds, s, d, npix, tiles);
-    } else {
-        auto kern = pw_kernel<T, NT, KS, 4, 3>;
-        HAT_LAUNCH(kern, grid, dim3(256), lds, s, d, npix, tiles);
     }
+    HAT_LAUNCH(kern, dim3(gx, d.n_slices, 1), dim3(WAVES * 64), lds, s, d, npix, tiles, scale_in_lds);
     return hat_check_launch();
+}
+
+template <typename T, int NT, int KS>
+int launch_pw(const HatConvDesc& d, hipStream_t s) {
+    size_t lds = (size_t)NT * KS * 64 * 8 * sizeof(T);  // a fragment is 64 lanes x 8 elements
+    if (lds > HAT_LDS_MAX) return HAT_EUNSUPPORTED;
+    const bool res = d.r1 != nullptr || d.r2 != nullptr;
+    int scale_in_lds = 0;
+    if (d.r2 != nullptr) {
+        const size_t tbl = (size_t)d.B * NT * 16 * sizeof(float);
+        if (tbl <= 16384 && lds + tbl <= HAT_LDS_MAX) { scale_in_lds = 1; lds += tbl; }
+    }
+    int wgs_per_cu = (int)(HAT_LDS_MAX / lds);
+    // waves per SIMD the register allocation is sized for: 3 workgroups x 4 waves -> 3, 2 x 4 -> 2, 1 x 8 -> 2; the
+    // residual variant keeps a tile's residual operands in registers and is sized for 2
+    wgs_per_cu = wgs_per_cu > (res ? 2 : 3) ? (res ? 2 : 3) : wgs_per_cu;
+    if (wgs_per_cu < 2) return res ? launch_pw_cfg<T, NT, KS, 8, 2, true>(d, s, lds, 1, scale_in_lds) : launch_pw_cfg<T, NT, KS, 8, 2, false>(d, s, lds, 1, 0);
+    if (wgs_per_cu == 2) return res ? launch_pw_cfg<T, NT, KS, 4, 2, true>(d, s, lds, 2, scale_in_lds) : launch_pw_cfg<T, NT, KS, 4, 2, false>(d, s, lds, 2, 0);
+    return launch_pw_cfg<T, NT, KS, 4, 3, false>(d, s, lds, 3, 0);
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -174,9 +213,12 @@ __global__ __launch_bounds__(WAVES * 64, MINW) void tap3_kernel(const HatConvDes
     const long HW = (long)H * W;
     const T* xb = reinterpret_cast<const T*>(d.x) + (size_t)b * HW * d.ldx;
     const T* zero = reinterpret_cast<const T*>(hat_zero_page);
-    f32x4 csum[NT];
+    f32x4 csum[NT], bias[NT];
 #pragma unroll
-    for (int nt = 0; nt < NT; ++nt) csum[nt] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int nt = 0; nt < NT; ++nt) {
+        csum[nt] = f32x4{0.f, 0.f, 0.f, 0.f};
+        bias[nt] = *reinterpret_cast<const f32x4*>(d.bias + nt * 16 + 4 * g);   // once, not one dependent load per tile
+    }
 
     const int stride = gridDim.x * WAVES;
     for (int tile = blockIdx.x * WAVES + wave; tile < tiles; tile += stride) {
@@ -222,7 +264,7 @@ __global__ __launch_bounds__(WAVES * 64, MINW) void tap3_kernel(const HatConvDes
             for (int nt = 0; nt < NT; ++nt) {
                 const int n = nt * 16 + 4 * g;
                 if (n < d.n_store) {
-                    f32x4 v = acc[nt] + *reinterpret_cast<const f32x4*>(d.bias + n);
+                    f32x4 v = acc[nt] + bias[nt];
                     if (d.act == HAT_ACT_GELU) {
 #pragma unroll
                         for (int r = 0; r < 4; ++r) v[r] = gelu_erf(v[r]);
