@@ -125,6 +125,10 @@ __host__ __device__ constexpr int lds_row_elems(int n, int es) {
     return slots * 16 / es;
 }
 
+// Workgroup barrier for LDS hand-offs that leaves global loads in flight.  __syncthreads() also drains vmcnt, which
+// turns every prefetch issued before it into a full memory round trip at the barrier.
+__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
 __device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
 
 // Launch status.  Every launch site first drains hipGetLastError(): the value is per-thread state that

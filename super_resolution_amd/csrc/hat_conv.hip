@@ -89,30 +89,58 @@ __global__ __launch_bounds__(WAVES * 64) void conv_kernel(const HatConvDesc d) {
         const T* xg0 = reinterpret_cast<const T*>(d.x0);
         const int ppp = Cin_p / VEC;
         const int total = npixh * ppp;
-        for (int i = tid; i < total; i += NTHR) {
-            const int q = i / ppp, c = (i - q * ppp) * VEC;
-            const int qy = q / TWH, qx = q - qy * TWH;
-            const int y = y0 - hl + qy, x = x0 - hl + qx;
-            u32x4 v = {0u, 0u, 0u, 0u};
-            if (y >= 0 && y < H && x >= 0 && x < W && c < Cin) {
-                const size_t pix = ((size_t)b * H + y) * W + x;
+        // SU pieces per thread per pass, every load unconditional (clamped address, zero selected afterwards): a load
+        // under a lane mask is waited for where it is issued, which made this loop one memory round trip per piece
+        constexpr int SU = 6;
+        for (int i0 = tid; i0 < total; i0 += NTHR * SU) {
+            u32x4 v[SU];
+            bool ok[SU];
+#pragma unroll
+            for (int u = 0; u < SU; ++u) {
+                const int i = min(i0 + u * NTHR, total - 1);
+                const int q = i / ppp, c = (i - q * ppp) * VEC;
+                const int qy = q / TWH, qx = q - qy * TWH;
+                const int y = y0 - hl + qy, x = x0 - hl + qx;
+                ok[u] = y >= 0 && y < H && x >= 0 && x < W && c < Cin;
+                const size_t pix = ((size_t)b * H + min(max(y, 0), H - 1)) * W + min(max(x, 0), W - 1);
                 const T* src = (xg0 != nullptr && c < d.c_split) ? xg0 + pix * d.ldx0 + c : xg + pix * d.ldx + c;
-                v = *reinterpret_cast<const u32x4*>(src);
+                v[u] = *reinterpret_cast<const u32x4*>(src);
             }
-            *reinterpret_cast<u32x4*>(Xs + (size_t)q * ldxs + c) = v;
+#pragma unroll
+            for (int u = 0; u < SU; ++u) {
+                const int i = i0 + u * NTHR;
+                if (i < total) {
+                    const int q = i / ppp, c = (i - q * ppp) * VEC;
+                    *reinterpret_cast<u32x4*>(Xs + (size_t)q * ldxs + c) = ok[u] ? v[u] : u32x4{0u, 0u, 0u, 0u};
+                }
+            }
         }
     } else if (d.x_mode == HAT_X_NHWC_F32) {
         const float* xg = reinterpret_cast<const float*>(d.x);
         const int gpp = Cin_p / 4;
         const int total = npixh * gpp;
-        for (int i = tid; i < total; i += NTHR) {
-            const int q = i / gpp, c = (i - q * gpp) * 4;
-            const int qy = q / TWH, qx = q - qy * TWH;
-            const int y = y0 - hl + qy, x = x0 - hl + qx;
-            f32x4 v = {0.f, 0.f, 0.f, 0.f};
-            if (y >= 0 && y < H && x >= 0 && x < W && c < Cin)
-                v = *reinterpret_cast<const f32x4*>(xg + (((size_t)b * H + y) * W + x) * d.ldx + c);
-            Vec4<T>::store(Xs + (size_t)q * ldxs + c, v);
+        constexpr int SU = 6;  // see the bf16/T branch above
+        for (int i0 = tid; i0 < total; i0 += NTHR * SU) {
+            f32x4 v[SU];
+            bool ok[SU];
+#pragma unroll
+            for (int u = 0; u < SU; ++u) {
+                const int i = min(i0 + u * NTHR, total - 1);
+                const int q = i / gpp, c = (i - q * gpp) * 4;
+                const int qy = q / TWH, qx = q - qy * TWH;
+                const int y = y0 - hl + qy, x = x0 - hl + qx;
+                ok[u] = y >= 0 && y < H && x >= 0 && x < W && c < Cin;
+                const size_t pix = ((size_t)b * H + min(max(y, 0), H - 1)) * W + min(max(x, 0), W - 1);
+                v[u] = *reinterpret_cast<const f32x4*>(xg + pix * d.ldx + min(c, Cin - 4));
+            }
+#pragma unroll
+            for (int u = 0; u < SU; ++u) {
+                const int i = i0 + u * NTHR;
+                if (i < total) {
+                    const int q = i / gpp, c = (i - q * gpp) * 4;
+                    Vec4<T>::store(Xs + (size_t)q * ldxs + c, ok[u] ? v[u] : f32x4{0.f, 0.f, 0.f, 0.f});
+                }
+            }
         }
     } else {  // HAT_X_NCHW_F32_MEAN: (x - mean[c]) * in_scale, zero padding applied AFTER the shift
         const float* xg = reinterpret_cast<const float*>(d.x);
@@ -142,30 +170,31 @@ __global__ __launch_bounds__(WAVES * 64) void conv_kernel(const HatConvDesc d) {
             for (int pt = 0; pt < PT; ++pt) acc[nt][pt] = f32x4{0.f, 0.f, 0.f, 0.f};
 
         const T* wslice = wg + (size_t)slice * NT * 16 * d.Kpad;
-        u32x4 wreg[WPT];
-        // register prefetch of one weight chunk (global -> VGPR now, VGPR -> LDS after the barrier)
-#define HAT_W_PREFETCH(chunk_)                                                                                        \
-    _Pragma("unroll") for (int j = 0; j < WPT; ++j) {                                                                 \
-        const int p_ = tid + j * NTHR;                                                                                \
-        if (WPIECES % NTHR == 0 || p_ < WPIECES)                                                                      \
-            wreg[j] = *reinterpret_cast<const u32x4*>(wslice + (size_t)(p_ / PPR) * d.Kpad + (size_t)(chunk_) * KC + (p_ % PPR) * VEC); \
-    }
-#define HAT_W_COMMIT()                                                                                                \
-    _Pragma("unroll") for (int j = 0; j < WPT; ++j) {                                                                 \
-        const int p_ = tid + j * NTHR;                                                                                \
-        if (WPIECES % NTHR == 0 || p_ < WPIECES)                                                                      \
-            *reinterpret_cast<u32x4*>(Ws + (p_ / PPR) * ldws + (p_ % PPR) * VEC) = wreg[j];                            \
-    }
+        // Weight chunks go global -> registers -> LDS, fetched TWO chunks ahead of their commit (one chunk of MFMAs is
+        // shorter than an L2 round trip) into two register sets used alternately; the loads are unconditional (clamped
+        // piece / chunk) and the barriers are LDS-only, so the fetches stay in flight across them.
+        u32x4 wra[WPT], wrb[WPT];
+        auto w_fetch = [&](int chunk, u32x4 (&wr)[WPT]) {
+            const int ch = chunk < nchunks ? chunk : nchunks - 1;
+#pragma unroll
+            for (int j = 0; j < WPT; ++j) {
+                const int p_ = min(tid + j * NTHR, WPIECES - 1);
+                wr[j] = *reinterpret_cast<const u32x4*>(wslice + (size_t)(p_ / PPR) * d.Kpad + (size_t)ch * KC + (p_ % PPR) * VEC);
+            }
+        };
+        auto w_commit = [&](const u32x4 (&wr)[WPT]) {
+#pragma unroll
+            for (int j = 0; j < WPT; ++j) {
+                const int p_ = tid + j * NTHR;
+                if (WPIECES % NTHR == 0 || p_ < WPIECES) *reinterpret_cast<u32x4*>(Ws + (p_ / PPR) * ldws + (p_ % PPR) * VEC) = wr[j];
+            }
+        };
 
         // this lane's position in flat K: k = 8*g (+32 per k-step) -> (tap, ci)
         int ci = 8 * g, tap = 0;
         while (ci >= Cin_p) { ci -= Cin_p; ++tap; }
 
-        HAT_W_PREFETCH(0)
-        for (int chunk = 0; chunk < nchunks; ++chunk) {
-            HAT_W_COMMIT()
-            __syncthreads();  // Ws (and, first time, Xs / tapoff) visible
-            if (chunk + 1 < nchunks) { HAT_W_PREFETCH(chunk + 1) }
+        auto k_chunk = [&]() {
 #pragma unroll
             for (int ks = 0; ks < KS; ++ks) {
                 const int poff = tapoff[tap < ntaps ? tap : ntaps - 1];
@@ -182,63 +211,98 @@ __global__ __launch_bounds__(WAVES * 64) void conv_kernel(const HatConvDesc d) {
                 ci += 32;
                 while (ci >= Cin_p) { ci -= Cin_p; ++tap; }
             }
-            __syncthreads();  // all waves done with Ws before the next commit / cs reuse
+        };
+
+        w_fetch(0, wra);
+        w_fetch(1, wrb);
+        for (int chunk = 0; chunk < nchunks; chunk += 2) {
+            w_commit(wra);
+            lds_barrier();  // Ws (and, first time, Xs / tapoff) visible
+            w_fetch(chunk + 2, wra);
+            k_chunk();
+            lds_barrier();  // all waves done with Ws before the next commit / cs reuse
+            if (chunk + 1 < nchunks) {
+                w_commit(wrb);
+                lds_barrier();
+                w_fetch(chunk + 3, wrb);
+                k_chunk();
+                lds_barrier();
+            }
         }
 
         // ---------------------------------- epilogue ------------------------------------------
+        // n-tiles are finished in groups of NG: the group's residual operands (r1, r2, r2's scale) are loaded in ONE
+        // batch before any of its stores — `out` may alias r1 (in-place residual), so loads placed between the stores
+        // are serialised one memory round trip at a time.
         const int nbase = slice * NT * 16;
         const bool want_cs = d.colsum != nullptr;
+        constexpr int NG = NT % 3 == 0 ? 3 : (NT % 2 == 0 ? 2 : 1);
+        const bool has_r1 = d.r1 != nullptr, has_r2 = d.r2 != nullptr;
 #pragma unroll
-        for (int nt = 0; nt < NT; ++nt) {
-            const int n = nbase + nt * 16 + 4 * g;  // first of this lane's 4 consecutive channels
-            const f32x4 bias = *reinterpret_cast<const f32x4*>(d.bias + n);
-            f32x4 csum = {0.f, 0.f, 0.f, 0.f};
+        for (int ng = 0; ng < NT; ng += NG) {
+            f32x4 r1v[NG][PT], scv[NG], biasv[NG];
+            typename Vec4<T>::raw_t r2v[NG][PT];
 #pragma unroll
-            for (int pt = 0; pt < PT; ++pt) {
-                const int y = y0 + wave * PT + pt, x = x0 + c16;
-                const bool valid = (y < H) && (x < W);
-                f32x4 v = acc[nt][pt] + bias;
-                if (d.act == HAT_ACT_GELU) {
+            for (int i = 0; i < NG; ++i) {
+                const int n = nbase + (ng + i) * 16 + 4 * g;
+                const int nc = min(n, d.n_store - 4) & ~3;
+                biasv[i] = *reinterpret_cast<const f32x4*>(d.bias + n);
+                if (has_r2) scv[i] = *reinterpret_cast<const f32x4*>(d.r2scale + (size_t)b * d.r2scale_bstride + nc);
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) v[r] = gelu_erf(v[r]);
-                } else if (d.act == HAT_ACT_LRELU) {
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) v[r] = v[r] >= 0.f ? v[r] : 0.01f * v[r];
+                for (int pt = 0; pt < PT; ++pt) {
+                    const size_t pixc = ((size_t)b * H + min(y0 + wave * PT + pt, H - 1)) * W + min(x0 + c16, W - 1);
+                    if (has_r1) r1v[i][pt] = *reinterpret_cast<const f32x4*>(d.r1 + pixc * d.ldr1 + nc);
+                    if (has_r2) r2v[i][pt] = Vec4<T>::load_raw(reinterpret_cast<const T*>(d.r2) + pixc * d.ldr2 + nc);
                 }
-                if (valid && n < d.n_store) {
-                    const size_t pix = ((size_t)b * H + y) * W + x;
-                    if (d.r1 != nullptr) v += *reinterpret_cast<const f32x4*>(d.r1 + pix * d.ldr1 + n);
-                    if (d.r2 != nullptr) {
-                        const f32x4 rv = Vec4<T>::load(reinterpret_cast<const T*>(d.r2) + pix * d.ldr2 + n);
-                        const f32x4 sc = *reinterpret_cast<const f32x4*>(d.r2scale + (size_t)b * d.r2scale_bstride + n);
-                        v += sc * rv;
-                    }
-                    if (d.out_mode == HAT_O_NHWC_T) {
-                        Vec4<T>::store(reinterpret_cast<T*>(d.out) + pix * d.ldo + n, v);
-                    } else if (d.out_mode == HAT_O_NHWC_F32) {
-                        *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(d.out) + pix * d.ldo + n) = v;
-                    } else if (d.out_mode == HAT_O_PIXSHUF_T) {
-                        const int r_ = d.ps_r, cps = d.n_store / (r_ * r_);
-                        const int ij = n / cps, cc = n - ij * cps;
-                        const int i_ = ij / r_, j_ = ij - i_ * r_;
-                        const size_t opix = ((size_t)b * H * r_ + (size_t)y * r_ + i_) * ((size_t)W * r_) + (size_t)x * r_ + j_;
-                        Vec4<T>::store(reinterpret_cast<T*>(d.out) + opix * d.ldo + cc, v);
-                    } else {  // HAT_O_NCHW_F32
-#pragma unroll
-                        for (int r = 0; r < 4; ++r)
-                            if (n + r < d.n_store)
-                                reinterpret_cast<float*>(d.out)[(((size_t)b * d.n_store + n + r) * H + y) * W + x] =
-                                    v[r] * d.out_scale + d.mean[(n + r) & 3];
-                    }
-                }
-                if (want_cs && valid) csum += v;
             }
-            if (want_cs) {
 #pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    float s = csum[r];
-                    s += __shfl_xor(s, 1); s += __shfl_xor(s, 2); s += __shfl_xor(s, 4); s += __shfl_xor(s, 8);
-                    if (c16 == 0) cs[wave * (NT * 16) + nt * 16 + 4 * g + r] = s;
+            for (int i = 0; i < NG; ++i) {
+                const int nt = ng + i;
+                const int n = nbase + nt * 16 + 4 * g;  // first of this lane's 4 consecutive channels
+                f32x4 csum = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int pt = 0; pt < PT; ++pt) {
+                    const int y = y0 + wave * PT + pt, x = x0 + c16;
+                    const bool valid = (y < H) && (x < W);
+                    f32x4 v = acc[nt][pt] + biasv[i];
+                    if (d.act == HAT_ACT_GELU) {
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) v[r] = gelu_erf(v[r]);
+                    } else if (d.act == HAT_ACT_LRELU) {
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) v[r] = v[r] >= 0.f ? v[r] : 0.01f * v[r];
+                    }
+                    if (valid && n < d.n_store) {
+                        const size_t pix = ((size_t)b * H + y) * W + x;
+                        if (has_r1) v += r1v[i][pt];
+                        if (has_r2) v += scv[i] * Vec4<T>::cvt(r2v[i][pt]);
+                        if (d.out_mode == HAT_O_NHWC_T) {
+                            Vec4<T>::store(reinterpret_cast<T*>(d.out) + pix * d.ldo + n, v);
+                        } else if (d.out_mode == HAT_O_NHWC_F32) {
+                            *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(d.out) + pix * d.ldo + n) = v;
+                        } else if (d.out_mode == HAT_O_PIXSHUF_T) {
+                            const int r_ = d.ps_r, cps = d.n_store / (r_ * r_);
+                            const int ij = n / cps, cc = n - ij * cps;
+                            const int i_ = ij / r_, j_ = ij - i_ * r_;
+                            const size_t opix = ((size_t)b * H * r_ + (size_t)y * r_ + i_) * ((size_t)W * r_) + (size_t)x * r_ + j_;
+                            Vec4<T>::store(reinterpret_cast<T*>(d.out) + opix * d.ldo + cc, v);
+                        } else {  // HAT_O_NCHW_F32
+#pragma unroll
+                            for (int r = 0; r < 4; ++r)
+                                if (n + r < d.n_store)
+                                    reinterpret_cast<float*>(d.out)[(((size_t)b * d.n_store + n + r) * H + y) * W + x] =
+                                        v[r] * d.out_scale + d.mean[(n + r) & 3];
+                        }
+                    }
+                    if (want_cs && valid) csum += v;
+                }
+                if (want_cs) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        float s = csum[r];
+                        s += __shfl_xor(s, 1); s += __shfl_xor(s, 2); s += __shfl_xor(s, 4); s += __shfl_xor(s, 8);
+                        if (c16 == 0) cs[wave * (NT * 16) + nt * 16 + 4 * g + r] = s;
+                    }
                 }
             }
         }
