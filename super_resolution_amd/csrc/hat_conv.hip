@@ -23,8 +23,8 @@ __host__ inline size_t conv_lds_bytes(const HatConvDesc& d, int waves, int pt, i
     const int cin_p = (d.Cin + 7) & ~7;
     const size_t xs = (size_t)(waves * pt + 2 * hl) * (16 + 2 * hl) * lds_row_elems(cin_p, es) * es;
     const size_t ws = (size_t)d.nt * 16 * lds_row_elems(kc, es) * es;
-    const size_t taps = ((size_t)d.ksize * d.ksize * 4 + 15) & ~(size_t)15;
-    return xs + ws + taps;
+    const size_t koff = ((size_t)(d.Kpad / 32) * 16 + 15) & ~(size_t)15;  // B-operand offset table: [k-step][4 lane groups]
+    return xs + ws + koff;
 }
 
 __host__ inline bool conv_pick(const HatConvDesc& d, TileCfg* out, size_t* lds) {
@@ -72,7 +72,7 @@ __global__ __launch_bounds__(WAVES * 64) void conv_kernel(const HatConvDesc d) {
     const int ldws = lds_row_elems(KC, sizeof(T));
     T* Xs = reinterpret_cast<T*>(smem);
     T* Ws = Xs + (size_t)THH * TWH * ldxs;
-    int* tapoff = reinterpret_cast<int*>(Ws + NT * 16 * ldws);
+    int* koff = reinterpret_cast<int*>(Ws + NT * 16 * ldws);
     float* cs = reinterpret_cast<float*>(Ws);  // column-sum scratch, reuses Ws after the K loop
 
     const int b = blockIdx.z;
@@ -80,7 +80,17 @@ __global__ __launch_bounds__(WAVES * 64) void conv_kernel(const HatConvDesc d) {
     const int H = d.H, W = d.W;
     const int ntaps = ks_ * ks_;
 
-    for (int t = tid; t < ntaps; t += NTHR) tapoff[t] = (t / ks_) * TWH + (t % ks_);
+    // koff[k-step][g]: element offset (inside Xs, relative to the output pixel) of the 8-channel group that lane group g
+    // feeds to that k-step: k = 32 * kstep + 8 * g = tap * Cin_p + ci  ->  (tap's row * TWH + tap's column) * ldxs + ci.
+    // K-padding steps past the last tap point at the last tap (their weights are zero).  One LDS read per k-step replaces
+    // per-lane (tap, ci) tracking, which cost more VALU time than the MFMAs of the one-n-tile layers.
+    for (int i = tid; i < (d.Kpad / 32) * 4; i += NTHR) {
+        const int k = 32 * (i >> 2) + 8 * (i & 3);
+        int tp = k / Cin_p;
+        const int cc = k - tp * Cin_p;
+        tp = tp < ntaps ? tp : ntaps - 1;
+        koff[i] = ((tp / ks_) * TWH + (tp % ks_)) * ldxs + cc;
+    }
 
     // ---------------- stage the haloed input tile (all channels), zero filled ------------------
     const int npixh = THH * TWH;
@@ -190,26 +200,22 @@ __global__ __launch_bounds__(WAVES * 64) void conv_kernel(const HatConvDesc d) {
             }
         };
 
-        // this lane's position in flat K: k = 8*g (+32 per k-step) -> (tap, ci)
-        int ci = 8 * g, tap = 0;
-        while (ci >= Cin_p) { ci -= Cin_p; ++tap; }
-
-        auto k_chunk = [&]() {
+        const T* xrow = Xs + (size_t)(wave * PT * TWH + c16) * ldxs;  // this lane's pixel of the wave's first tile row
+        auto k_chunk = [&](int chunk) {
+            int ko[KS];
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) ko[ks] = koff[(chunk * KS + ks) * 4 + g];
 #pragma unroll
             for (int ks = 0; ks < KS; ++ks) {
-                const int poff = tapoff[tap < ntaps ? tap : ntaps - 1];
                 typename M::frag_t bf[PT];
 #pragma unroll
-                for (int pt = 0; pt < PT; ++pt)
-                    bf[pt] = M::load(Xs + (size_t)((wave * PT + pt) * TWH + c16 + poff) * ldxs + ci);
+                for (int pt = 0; pt < PT; ++pt) bf[pt] = M::load(xrow + (size_t)pt * TWH * ldxs + ko[ks]);
 #pragma unroll
                 for (int nt = 0; nt < NT; ++nt) {
                     const typename M::frag_t af = M::load(Ws + (nt * 16 + c16) * ldws + ks * 32 + 8 * g);
 #pragma unroll
                     for (int pt = 0; pt < PT; ++pt) acc[nt][pt] = M::mma(af, bf[pt], acc[nt][pt]);
                 }
-                ci += 32;
-                while (ci >= Cin_p) { ci -= Cin_p; ++tap; }
             }
         };
 
@@ -217,15 +223,15 @@ __global__ __launch_bounds__(WAVES * 64) void conv_kernel(const HatConvDesc d) {
         w_fetch(1, wrb);
         for (int chunk = 0; chunk < nchunks; chunk += 2) {
             w_commit(wra);
-            lds_barrier();  // Ws (and, first time, Xs / tapoff) visible
+            lds_barrier();  // Ws (and, first time, Xs / koff) visible
             w_fetch(chunk + 2, wra);
-            k_chunk();
+            k_chunk(chunk);
             lds_barrier();  // all waves done with Ws before the next commit / cs reuse
             if (chunk + 1 < nchunks) {
                 w_commit(wrb);
                 lds_barrier();
                 w_fetch(chunk + 3, wrb);
-                k_chunk();
+                k_chunk(chunk + 1);
                 lds_barrier();
             }
         }
