@@ -40,6 +40,7 @@ MODELS = {
                   upsampler="pixelshuffle", resi_connection="1conv"),
 }
 MFMA_PEAK_TFLOPS = {"bf16": 2500.0, "f32": 157.3}  # dense peaks, /opt/skills/guides/MI355X_MICROARCH.md
+HBM_PEAK_GBS = 8000.0  # HBM3E spec peak (same guide; ~6300 GB/s is what streaming kernels reach)
 W_SEED, X_SEED = 1234, 7
 
 
@@ -176,12 +177,13 @@ def main():
                 else:
                     tp.run_tile(x, net, tiles[tp.assign(tiles, world)[0][0]], s)
                 torch.cuda.synchronize()
-                for name, fl, a, b, tag in rec:
+                for name, fl, a, b, tag, nb in rec:
                     ms = a.elapsed_time(b)
-                    e = agg.setdefault(name, [0, 0.0, 0.0])
+                    e = agg.setdefault(name, [0, 0.0, 0.0, 0.0])
                     e[0] += 1
                     e[1] += ms
                     e[2] += fl
+                    e[3] += nb
                     if tag:
                         e2 = layers.setdefault(name + " | " + tag, [0, 0.0, 0.0])
                         e2[0] += 1
@@ -196,12 +198,32 @@ def main():
                 print(f"# {e2[1] / reps:8.3f} ms/step  {e2[0] // reps:3d}x {e2[1] / e2[0]:7.4f} ms  "
                       f"{e2[2] / (e2[1] * 1e-3) / 1e12 if e2[2] else 0:7.1f} TF  {k}", file=sys.stderr)
         dom, e = max(agg.items(), key=lambda kv: kv[1][1])
-        achieved = e[2] / (e[1] * 1e-3) / 1e12
-        peak = MFMA_PEAK_TFLOPS[args.dtype]
-        roofline = {"bound": "mfma", "kernel": dom, "achieved": round(achieved, 2), "peak": peak, "unit": "TFLOP/s",
-                    "frac": round(achieved / peak, 4), "traffic": None, "launches_per_step": e[0] // reps,
-                    "avg_launch_ms": round(e[1] / e[0], 4), "flop_per_launch": round(e[2] / e[0] / 1e9, 3),
-                    "flop_unit": "GFLOP (algorithmic, 2*MAC)"}
+        avg_s = e[1] / e[0] * 1e-3
+        tflops = e[2] / e[0] / avg_s / 1e12
+        peak_tf = MFMA_PEAK_TFLOPS[args.dtype]
+        if e[3] > 0 and (e[2] / e[3]) < peak_tf * 1e12 / (HBM_PEAK_GBS * 1e9):
+            # arithmetic intensity below the machine balance: the HBM roof is the lower one for this kernel
+            gbs = e[3] / e[0] / avg_s / 1e9
+            roofline = {"bound": "hbm", "kernel": dom, "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                        "frac": round(gbs / HBM_PEAK_GBS, 4), "traffic": None,
+                        "bytes_per_launch": round(e[3] / e[0]), "bytes_unit": "algorithmic HBM bytes (DESIGN.md, hat_ffn)",
+                        "mfma_tflops": round(tflops, 2), "mfma_frac": round(tflops / peak_tf, 4),
+                        "intensity_flop_per_byte": round(e[2] / e[3], 1)}
+        else:
+            roofline = {"bound": "mfma", "kernel": dom, "achieved": round(tflops, 2), "peak": peak_tf, "unit": "TFLOP/s",
+                        "frac": round(tflops / peak_tf, 4), "traffic": None}
+        roofline.update({"launches_per_step": e[0] // reps, "avg_launch_ms": round(e[1] / e[0], 4),
+                         "flop_per_launch": round(e[2] / e[0] / 1e9, 3), "flop_unit": "GFLOP (algorithmic, 2*MAC)"})
+        # HBM bytes per launch from the PMC counters: measured in separate rocprofv3 --pmc passes (profiles/README.md)
+        # and recorded in profiles/; quoted only when the recording is of this exact workload
+        try:
+            with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01_hbm_traffic.json")) as f:
+                tr = json.load(f)
+            if tr.get("workload") == [args.model, s, H, W, args.dtype] and dom in tr.get("kernels", {}):
+                roofline["traffic"] = tr["kernels"][dom]["hbm_bytes_per_launch"]
+                roofline["traffic_source"] = "profiles/r01_hbm_traffic.json (FETCH_SIZE x2 + WRITE_SIZE, separate --pmc passes)"
+        except (OSError, ValueError):
+            pass
     if world > 1:
         dist.barrier()
 

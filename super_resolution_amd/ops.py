@@ -51,14 +51,15 @@ class profile:
         return False
 
 
-def _timed(name, flops, fn, tag=""):
+def _timed(name, flops, fn, tag="", nbytes=0.0):
+    """nbytes: ALGORITHMIC HBM bytes of the launch (each operand read once, each result written once)."""
     if _prof is None:
         return fn()
     s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     s.record()
     r = fn()
     e.record()
-    _prof.append((name, float(flops), s, e, tag))
+    _prof.append((name, float(flops), s, e, tag, float(nbytes)))
     return r
 
 
@@ -312,7 +313,12 @@ def ffn(pf: PackedFFN, t_in, t_out, ln_g, ln_b, *, B: int, H: int, W: int, dtype
         d.ln1_g, d.ln1_b, d.n_out, d.ldn = _ptr(ln1[0]), _ptr(ln1[1]), _ptr(n_out), ldn
         d.gap_out, d.gap_c = (_ptr(gap_out) if gap_c else None), gap_c
     flops = B * H * W * (2.0 * pf.C * 2 * pf.hid + 2.0 * 9 * 2 * pf.hid + 2.0 * pf.hid * pf.C)
-    _timed(f"ffn_kernel<{_TNAME[dtype]}>", flops, lambda: _lib.check(lib.hat_ffn(C.byref(d), _stream()), "hat_ffn"))
+    # algorithmic HBM bytes per pixel: t_in read once (fp32), t_out written (fp32), the next block's LayerNorm output
+    # written (T); weights and the on-chip hidden tensor do not count
+    es = 2 if dtype == HAT_BF16 else 4
+    nbytes = B * H * W * (4.0 * pf.C + 4.0 * pf.C + (es * ldn if ln1 is not None else 0))
+    _timed(f"ffn_kernel<{_TNAME[dtype]}>", flops, lambda: _lib.check(lib.hat_ffn(C.byref(d), _stream()), "hat_ffn"),
+           nbytes=nbytes)
 
 
 # ------------------------------------------------------------------------------------------------
