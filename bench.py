@@ -93,7 +93,7 @@ def main():
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32"])
     ap.add_argument("--mode", default="tiles", choices=["tiles", "frames"], help="N>1: one frame cut in tiles, or one frame per rank")
     ap.add_argument("--tile-pad", type=int, default=32)
-    ap.add_argument("--cpu-crop", type=int, default=160, help="side of the crop timed on the CPU (0 disables the baseline)")
+    ap.add_argument("--cpu-crop", type=int, default=256, help="side of the crop timed on the CPU (0 disables the baseline)")
     ap.add_argument("--no-kernel-profile", action="store_true")
     args = ap.parse_args()
 

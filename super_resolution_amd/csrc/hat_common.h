@@ -125,6 +125,16 @@ __host__ __device__ constexpr int lds_row_elems(int n, int es) {
     return slots * 16 / es;
 }
 
+// Sum over the 16 lanes of a DPP row (lanes 16r .. 16r+15), result in every lane: four v_add_f32 with row_ror
+// modifiers instead of four ds_bpermute round trips (__shfl_xor).  Deterministic; order differs from a butterfly.
+__device__ __forceinline__ float row_sum16(float s) {
+    s += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, s), 0x128, 0xf, 0xf, false));
+    s += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, s), 0x124, 0xf, 0xf, false));
+    s += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, s), 0x122, 0xf, 0xf, false));
+    s += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, s), 0x121, 0xf, 0xf, false));
+    return s;
+}
+
 // Workgroup barrier for LDS hand-offs that leaves global loads in flight.  __syncthreads() also drains vmcnt, which
 // turns every prefetch issued before it into a full memory round trip at the barrier.
 __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }

@@ -306,7 +306,7 @@ __global__ __launch_bounds__(WAVES * 64) void conv_kernel(const HatConvDesc d) {
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
                         float s = csum[r];
-                        s += __shfl_xor(s, 1); s += __shfl_xor(s, 2); s += __shfl_xor(s, 4); s += __shfl_xor(s, 8);
+                        s = row_sum16(s);
                         if (c16 == 0) cs[wave * (NT * 16) + nt * 16 + 4 * g + r] = s;
                     }
                 }

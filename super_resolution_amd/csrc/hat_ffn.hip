@@ -129,7 +129,7 @@ __global__ __launch_bounds__(WAVES * 64, MINW) void ffn_kernel(const HatFfnDesc 
                     if (!(inside[u] && 4 * j + 64 * v < C)) xv[u][v] = f32x4{0.f, 0.f, 0.f, 0.f};
                     s += (xv[u][v][0] + xv[u][v][1]) + (xv[u][v][2] + xv[u][v][3]);
                 }
-                s += __shfl_xor(s, 1); s += __shfl_xor(s, 2); s += __shfl_xor(s, 4); s += __shfl_xor(s, 8);
+                s = row_sum16(s);
                 const float mean = s * invC;
                 float q = 0.f;
 #pragma unroll
@@ -139,7 +139,7 @@ __global__ __launch_bounds__(WAVES * 64, MINW) void ffn_kernel(const HatFfnDesc 
                         for (int r = 0; r < 4; ++r) { const float dl = xv[u][v][r] - mean; q += dl * dl; }
                     }
                 }
-                q += __shfl_xor(q, 1); q += __shfl_xor(q, 2); q += __shfl_xor(q, 4); q += __shfl_xor(q, 8);
+                q = row_sum16(q);
                 const float rstd = 1.0f / sqrtf(q * invC + 1e-5f);
                 if (hp < NPH) {
 #pragma unroll
@@ -443,7 +443,7 @@ __global__ __launch_bounds__(WAVES * 64, MINW) void ffn_kernel(const HatFfnDesc 
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             float s = gapv[r];
-            s += __shfl_xor(s, 1); s += __shfl_xor(s, 2); s += __shfl_xor(s, 4); s += __shfl_xor(s, 8);
+            s = row_sum16(s);
             if (c16 == 0) red[wave * 16 + 4 * g + r] = s;
         }
         __syncthreads();

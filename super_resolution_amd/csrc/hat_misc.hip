@@ -43,7 +43,7 @@ __global__ __launch_bounds__(256) void ln_kernel(const float* __restrict__ x, Ou
             if (pv && c < C) xv[v] = *reinterpret_cast<const f32x4*>(xb + (size_t)p * C + c);
             s += (xv[v][0] + xv[v][1]) + (xv[v][2] + xv[v][3]);
         }
-        s += __shfl_xor(s, 1); s += __shfl_xor(s, 2); s += __shfl_xor(s, 4); s += __shfl_xor(s, 8);
+        s = row_sum16(s);
         const float mean = s * invC;
         float q = 0.f;
 #pragma unroll
@@ -54,7 +54,7 @@ __global__ __launch_bounds__(256) void ln_kernel(const float* __restrict__ x, Ou
                 for (int r = 0; r < 4; ++r) { const float dlt = xv[v][r] - mean; q += dlt * dlt; }
             }
         }
-        q += __shfl_xor(q, 1); q += __shfl_xor(q, 2); q += __shfl_xor(q, 4); q += __shfl_xor(q, 8);
+        q = row_sum16(q);
         const float rstd = 1.0f / sqrtf(q * invC + 1e-5f);
 #pragma unroll
         for (int v = 0; v < NV; ++v) {

@@ -287,7 +287,7 @@ __global__ __launch_bounds__(WAVES * 64, MINW) void tap3_kernel(const HatConvDes
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 float sv = csum[nt][r];
-                sv += __shfl_xor(sv, 1); sv += __shfl_xor(sv, 2); sv += __shfl_xor(sv, 4); sv += __shfl_xor(sv, 8);
+                sv = row_sum16(sv);
                 if (c16 == 0) red[wave * (NT * 16) + nt * 16 + 4 * g + r] = sv;
             }
         }
