@@ -58,7 +58,7 @@ __device__ __forceinline__ float silu_exact(float x) { return x / (1.0f + expf(-
 
 // DBG is a timing-ablation mask used only by tools/ubench_ffn.hip (the library instantiates DBG = 0):
 //   1 skip LN stage, 2 skip fc1 MFMA loop, 4 skip the dw MFMAs, 8 skip gate math, 16 skip fc2 MFMAs,
-//   32 skip all weight-fragment loads
+//   32 skip all weight-fragment loads, 64 per-phase s_memtime totals of every wave -> gap_out[wg][wave][8]
 // MINW = waves per SIMD the register allocation must allow (2 when two workgroups' LDS fit one CU)
 template <typename T, int WAVES, int NT, int KS, bool MSWZ, int MINW, int DBG = 0>
 __global__ __launch_bounds__(WAVES * 64, MINW) void ffn_kernel(const HatFfnDesc d) {
@@ -92,6 +92,16 @@ __global__ __launch_bounds__(WAVES * 64, MINW) void ffn_kernel(const HatFfnDesc 
     const float* tin = d.t_in + (size_t)b * H * W * C;
     const int hid_p = d.chunks * CH;
 
+    long long tph[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    long long tlast = 0;
+    auto stamp = [&](int slot) {
+        if constexpr (DBG & 64) {
+            const long long now = (long long)__builtin_amdgcn_s_memtime();
+            tph[slot] += now - tlast;
+            tlast = now;
+        }
+    };
+    if constexpr (DBG & 64) tlast = (long long)__builtin_amdgcn_s_memtime();
     // ------------------------------ stage 0: LayerNorm2 -> Ms --------------------------------
     // Every global load here is unconditional (clamped address, result discarded by a select): a load under a lane
     // mask whose result merges with a default makes the compiler wait for it right where it is issued, which turned
@@ -140,20 +150,19 @@ __global__ __launch_bounds__(WAVES * 64, MINW) void ffn_kernel(const HatFfnDesc 
                     }
                 }
                 q = row_sum16(q);
-                const float rstd = 1.0f / sqrtf(q * invC + 1e-5f);
+                const float rstd = BF ? __builtin_amdgcn_rsqf(q * invC + 1e-5f) : 1.0f / sqrtf(q * invC + 1e-5f);
                 if (hp < NPH) {
 #pragma unroll
-                    for (int v = 0; v < 3; ++v) {
+                    for (int v = 0; v < 3; ++v) {   // selects, not branches; lanes past the row's end rewrite its last (zero) group
                         const int c = 4 * j + 64 * v;
-                        if (c < Kp) {
-                            f32x4 o = {0.f, 0.f, 0.f, 0.f};
-                            if (inside[u] && c < C) {
+                        if (64 * v < Kp) {
+                            const bool live = inside[u] && c < C;
+                            f32x4 o;
 #pragma unroll
-                                for (int r = 0; r < 4; ++r) o[r] = (xv[u][v][r] - mean) * rstd * gmv[v][r] + btv[v][r];
-                            } else if (inside[u] && c == C) {
-                                o[0] = 1.0f;  // bias column (C % 4 == 0)
-                            }
-                            Vec4<T>::store(Ms + (size_t)hp * ldm + ms_slot(hp, c / VECN) + (c % VECN), o);
+                            for (int r = 0; r < 4; ++r) o[r] = live ? (xv[u][v][r] - mean) * rstd * gmv[v][r] + btv[v][r] : 0.f;
+                            const int cs = min(c, Kp - 4);           // (cs >= C whenever it differs from c)
+                            if (inside[u] && cs == C) o[0] = 1.0f;   // bias column (C % 4 == 0)
+                            Vec4<T>::store(Ms + (size_t)hp * ldm + ms_slot(hp, cs / VECN) + (cs % VECN), o);
                         }
                     }
                 }
@@ -259,7 +268,9 @@ __global__ __launch_bounds__(WAVES * 64, MINW) void ffn_kernel(const HatFfnDesc 
     // constant-one row of Us (the depthwise bias is "tap 9" times 1)
     for (int i = tid; i < 2 * CH; i += NTHR) Us[(size_t)NPH * 2 * CH + i] = to_T<T>(1.0f);
     load_a1(0);
+    stamp(0);
     __syncthreads();  // Ms complete
+    stamp(1);
 
     for (int chunk = 0; chunk < d.chunks; ++chunk) {
         // ================================ phase A: fc1 -> Us ====================================
@@ -279,6 +290,7 @@ __global__ __launch_bounds__(WAVES * 64, MINW) void ffn_kernel(const HatFfnDesc 
 #pragma unroll
             for (int i = 0; i < NPTW; ++i) {
                 if (i + 1 < NPTW) load_b(i + 1, bnxt);  // next tile's operands are in flight during these MFMAs
+                __builtin_amdgcn_sched_barrier(0);      // (hipcc sinks the reads to 1-2 MFMAs before their use otherwise)
                 f32x4 acc[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
 #pragma unroll
                 for (int ks = 0; ks < ((DBG & 2) ? 0 : KS); ++ks) {
@@ -297,29 +309,38 @@ __global__ __launch_bounds__(WAVES * 64, MINW) void ffn_kernel(const HatFfnDesc 
                 }
             }
         }
+        stamp(2);
         __syncthreads();  // Us complete
+        stamp(3);
 
         // ============ phase B: depthwise 3x3 as MFMA with diagonal weights (this wave's two rows) ============
         f32x4 dacc[4][2];
 #pragma unroll
         for (int gi = 0; gi < 4; ++gi) { dacc[gi][0] = f32x4{0.f, 0.f, 0.f, 0.f}; dacc[gi][1] = dacc[gi][0]; }
-        frag_t a2[NT];  // fc2 weights: issued now, consumed after the gate math
+        frag_t a2[NT];  // fc2 weights: issued half-way through the depthwise steps, consumed after the gate math
+        auto load_a2 = [&]() {
 #pragma unroll
-        for (int nt = 0; nt < NT; ++nt)
-            a2[nt] = (DBG & 32) ? M::zero() : M::load(w2f + (((size_t)chunk * NT + nt) * 64 + lane) * 8);
+            for (int nt = 0; nt < NT; ++nt)
+                a2[nt] = (DBG & 32) ? M::zero() : M::load(w2f + (((size_t)chunk * NT + nt) * 64 + lane) * 8);
+        };
+        if constexpr (DBG & 4) load_a2();
         if constexpr (!(DBG & 4)) {
-            // 20 steps (tap pair, channel group), two MFMAs each (the wave's two rows); operands two steps ahead
-            constexpr int NSTEP = NPAIR * 4, DEPTH = 3;
+            // 20 steps (tap pair, channel group), two MFMAs each (the wave's two rows); operands AHEAD steps ahead
+            // (an LDS read takes ~8 MFMA times), pinned there: hipcc otherwise sinks each read to one MFMA before
+            // its use and every step stalls on it
+            constexpr int NSTEP = NPAIR * 4, AHEAD = BF ? 3 : 2, DEPTH = AHEAD + 1;
             frag_t ub[DEPTH][2];
             auto issue = [&](int st) {
                 ub[st % DEPTH][0] = ldu(st >> 2, 0, st & 3);
                 ub[st % DEPTH][1] = ldu(st >> 2, 1, st & 3);
             };
-            issue(0);
-            issue(1);
+#pragma unroll
+            for (int st = 0; st < AHEAD; ++st) issue(st);
 #pragma unroll
             for (int st = 0; st < NSTEP; ++st) {
-                if (st + 2 < NSTEP) issue(st + 2);
+                if (st + AHEAD < NSTEP) issue(st + AHEAD);
+                if (st == NSTEP / 2) load_a2();
+                __builtin_amdgcn_sched_barrier(0);
                 const int pr = st >> 2, gi = st & 3;
                 // A = [diag(w_tap0) | diag(w_tap1)]: this lane's row (channel c16 of the group) has ONE non-zero
                 // element, at position jstar of its 8-wide k group (the host zeroes the weight in lanes whose k
@@ -338,6 +359,7 @@ __global__ __launch_bounds__(WAVES * 64, MINW) void ffn_kernel(const HatFfnDesc 
                 dacc[gi][1] = M::mma(af, ub[st % DEPTH][1], dacc[gi][1]);
             }
         }
+        stamp(4);
         // ================================ phase C: gate + fc2 ===================================
         if (chunk + 1 < d.chunks) load_a1(chunk + 1);  // next chunk's fc1 weights: in flight during gate + fc2
 #ifdef HAT_FFN_DEBUG_DUMP
@@ -378,7 +400,9 @@ __global__ __launch_bounds__(WAVES * 64, MINW) void ffn_kernel(const HatFfnDesc 
                 for (int nt = 0; nt < NT; ++nt) acc2[nt][pt] = M::mma(a2[nt], gf, acc2[nt][pt]);
             }
         }
+        stamp(5);
         __syncthreads();  // every wave is done reading Us before the next chunk's fc1 overwrites it
+        stamp(6);
     }
 
     // ----------------------------------- epilogue ------------------------------------------------
@@ -437,6 +461,14 @@ __global__ __launch_bounds__(WAVES * 64, MINW) void ffn_kernel(const HatFfnDesc 
                 }
             }
         }
+    }
+    if constexpr (DBG & 64) {
+        stamp(7);
+        if (lane == 0) {
+            const size_t wg = ((size_t)blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;
+            for (int i = 0; i < 8; ++i) d.gap_out[(wg * WAVES + wave) * 8 + i] = (float)tph[i];
+        }
+        return;
     }
     if (do_ln && d.gap_out != nullptr) {
         float* red = reinterpret_cast<float*>(Us);  // Us is free after the last barrier of the chunk loop

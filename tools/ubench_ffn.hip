@@ -11,7 +11,7 @@ __global__ void fill(float* p, size_t n, float s) { size_t i = blockIdx.x * (siz
 __global__ void fillh(bf16_t* p, size_t n, float s) { size_t i = blockIdx.x * (size_t)256 + threadIdx.x; if (i < n) p[i] = (bf16_t)(s * (float)((i * 2654435761u) % 1000) / 1000.f - 0.5f * s); }
 
 template <int WV, int DBG> float run(const HatFfnDesc& d, int iters) {
-    auto kern = ffn_kernel<bf16_t, WV, 9, 5, true, (WV == 4 ? 2 : 1), DBG>;
+    auto kern = ffn_kernel<bf16_t, WV, 9, 5, true, 2, DBG>;
     const size_t lds = ffn_lds_bytes<bf16_t, WV, true>(d.C);
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     dim3 grid((d.W + 15) / 16, (d.H + 2 * WV - 1) / (2 * WV), d.B);
@@ -41,6 +41,21 @@ int main() {
     d.t_in = tin; d.t_out = tout; d.ln_g = vec; d.ln_b = vec + 256; d.w1f = w1f; d.b1 = vec + 512; d.dww = dww; d.dwb = vec + 2048;
     d.w2f = w2f; d.b2 = vec + 4096; d.B = 1; d.H = H; d.W = W; d.C = C; d.chunks = chunks; d.dtype = HAT_BF16;
     const int it = 5;
+    if (getenv("UB_PHASES")) {
+        run<4, 0>(d, 300);
+        const size_t nwg = (size_t)((W + 15) / 16) * ((H + 7) / 8);
+        float* ph; CK(hipMalloc(&ph, nwg * 4 * 8 * 4));
+        d.gap_out = ph;
+        printf("instrumented run %.3f ms\n", run<4, 64>(d, 2));
+        std::vector<float> hp(nwg * 4 * 8);
+        CK(hipMemcpy(hp.data(), ph, hp.size() * 4, hipMemcpyDeviceToHost));
+        const char* names[8] = {"LN stage", "barrier after LN", "phase A (fc1)", "barrier after A", "phase B (dw)", "phase C (gate+fc2)", "barrier after C", "epilogue"};
+        double tot[8] = {0}; double all = 0;
+        for (size_t i = 0; i < nwg * 4; ++i) for (int k = 0; k < 8; ++k) { tot[k] += hp[i * 8 + k]; all += hp[i * 8 + k]; }
+        for (int k = 0; k < 8; ++k) printf("  %-22s %10.0f cycles/wave  (%.1f%%)\n", names[k], tot[k] / (nwg * 4), 100.0 * tot[k] / all);
+        printf("  total %.0f cycles/wave\n", all / (nwg * 4));
+        return 0;
+    }
     if (getenv("UB_ONLY_FULL")) { printf("full %.3f ms\n", run<4, 0>(d, 3)); return 0; }
 #define ROW(WV, M, label) printf("%-34s %.3f ms\n", label, run<WV, M>(d, it))
     printf("---- 4 waves (8x16 tile, 2 WG/CU)\n");
