@@ -77,6 +77,14 @@ typedef struct HatConvDesc {
     float in_scale, out_scale;
     float mean[4];        /* HAT_X_NCHW_F32_MEAN: x = (x - mean[c]) * in_scale;  HAT_O_NCHW_F32: v*out_scale + mean[n] */
     int32_t dtype;
+    /* hat_linear only (n_slices == 1, n_store == channels): also emit LayerNorm(v) (eps 1e-5) of the finished pixel,
+     * i.e. the nn.LayerNorm that consumes this layer's output (hat_arch.py:214 after :236; :306 after :391), as T
+     * rows of ld_ln elements.  ln_ones != 0: element [n_store] of every row is 1.0 and the rest up to ld_ln is 0 —
+     * the image hat_ffn's m_in expects.  ln_out == NULL: off. */
+    int32_t ld_ln, ln_ones;
+    const float* ln_g;
+    const float* ln_b;
+    void* ln_out;
 } HatConvDesc;
 
 /* Number of spatial tiles hat_conv uses for (H, W, Cin, ksize, nt, dtype): the leading dimension of `colsum`. */
@@ -192,6 +200,11 @@ typedef struct HatFfnDesc {
     int32_t chunks;      /* hid_p / 32 */
     int32_t ldn, gap_c;
     int32_t dtype;
+    /* optional: LayerNorm2(t_in) already computed by the producer (hat_linear's ln_out with ln_ones): T rows of
+     * ldm_in >= 32*ceil((C+1)/32) elements = [LN (C) | 1.0 | zeros].  The kernel then copies instead of normalising
+     * (ln_g / ln_b are ignored). */
+    int32_t ldm_in;
+    const void* m_in;
 } HatFfnDesc;
 
 int hat_ffn_tiles(const HatFfnDesc* d, int32_t* tiles_out);

@@ -39,6 +39,8 @@ class HatConvDesc(C.Structure):
         ("in_scale", C.c_float), ("out_scale", C.c_float),
         ("mean", C.c_float * 4),
         ("dtype", C.c_int32),
+        ("ld_ln", C.c_int32), ("ln_ones", C.c_int32),
+        ("ln_g", C.c_void_p), ("ln_b", C.c_void_p), ("ln_out", C.c_void_p),
     ]
 
 
@@ -51,6 +53,7 @@ class HatFfnDesc(C.Structure):
         ("n_out", C.c_void_p), ("gap_out", C.c_void_p),
         ("B", C.c_int32), ("H", C.c_int32), ("W", C.c_int32), ("C", C.c_int32),
         ("chunks", C.c_int32), ("ldn", C.c_int32), ("gap_c", C.c_int32), ("dtype", C.c_int32),
+        ("ldm_in", C.c_int32), ("m_in", C.c_void_p),
     ]
 
 

@@ -28,6 +28,9 @@
 
 namespace {
 
+// source of out-of-image halo rows on the pre-normalised (m_in) path
+__device__ __attribute__((aligned(16))) unsigned hat_ffn_zero_page[4] = {0, 0, 0, 0};
+
 constexpr int CH = 32;        // hidden channels per chunk (a-part); the chunk also carries CH gate channels
 constexpr int HALO_W = 18;    // 16 + 2
 constexpr int NPAIR = 5;      // 9 taps, two per k-step
@@ -106,7 +109,33 @@ __global__ __launch_bounds__(WAVES * 64, MINW) void ffn_kernel(const HatFfnDesc 
     // Every global load here is unconditional (clamped address, result discarded by a select): a load under a lane
     // mask whose result merges with a default makes the compiler wait for it right where it is issued, which turned
     // this stage into one memory round trip per load.  gamma/beta are read once, not per pixel.
-    if constexpr (!(DBG & 1)) {
+    if (d.m_in != nullptr) {
+        // The producer (hat_linear with ln_out / ln_ones) already wrote LayerNorm2(t_in) as rows [LN (C) | 1.0 | 0...]:
+        // stage 0 is a copy of the haloed tile, 16 bytes per item, all loads issued before the first LDS store;
+        // out-of-image rows come from a zero page.
+        constexpr int SPR = Kp / VECN;                  // 16-byte slots per Ms row
+        constexpr int NIT = (NPH * SPR + NTHR - 1) / NTHR;
+        const T* mg = reinterpret_cast<const T*>(d.m_in) + (size_t)b * H * W * d.ldm_in;
+        u32x4 cv[NIT];
+#pragma unroll
+        for (int it = 0; it < NIT; ++it) {
+            const int i = min(tid + it * NTHR, NPH * SPR - 1);
+            const int hp = i / SPR, sl = i - hp * SPR;
+            const int hy = hp / HALO_W, hx = hp - hy * HALO_W;
+            const int y = y0 - 1 + hy, x = x0 - 1 + hx;
+            const bool inside = y >= 0 && y < H && x >= 0 && x < W;
+            const T* src = inside ? mg + ((size_t)y * W + x) * d.ldm_in + sl * VECN : reinterpret_cast<const T*>(hat_ffn_zero_page);
+            cv[it] = *reinterpret_cast<const u32x4*>(src);
+        }
+#pragma unroll
+        for (int it = 0; it < NIT; ++it) {
+            const int i = tid + it * NTHR;
+            if (i < NPH * SPR) {
+                const int hp = i / SPR, sl = i - hp * SPR;
+                *reinterpret_cast<u32x4*>(Ms + (size_t)hp * ldm + ms_slot(hp, sl)) = cv[it];
+            }
+        }
+    } else if constexpr (!(DBG & 1)) {
         const int j = tid & 15, grp = tid >> 4;
         constexpr int NGRP = NTHR / 16;
         const float invC = 1.0f / (float)C;
@@ -525,9 +554,10 @@ extern "C" int hat_ffn_tiles(const HatFfnDesc* d, int32_t* tiles_out) {
 extern "C" int hat_ffn(const HatFfnDesc* dp, void* stream) {
     if (!dp) return HAT_EINVAL;
     const HatFfnDesc& d = *dp;
-    if (!d.t_in || !d.t_out || d.t_in == d.t_out || !d.ln_g || !d.ln_b || !d.w1f || !d.b1 || !d.dww || !d.dwb || !d.w2f || !d.b2)
+    if (!d.t_in || !d.t_out || d.t_in == d.t_out || ((!d.ln_g || !d.ln_b) && !d.m_in) || !d.w1f || !d.b1 || !d.dww || !d.dwb || !d.w2f || !d.b2)
         return HAT_EINVAL;
     if (d.B < 1 || d.H < 1 || d.W < 1 || d.C < 8 || d.C % 4 || d.chunks < 1) return HAT_EINVAL;
+    if (d.m_in && (d.ldm_in < ffn_kp(d.C) || d.ldm_in % (d.dtype == HAT_BF16 ? 8 : 4))) return HAT_EINVAL;
     if (d.ln1_g && (!d.ln1_b || !d.n_out || d.ldn < d.C || d.ldn % 4 || d.gap_c < 0 || d.gap_c > 16 || d.gap_c % 4)) return HAT_EINVAL;
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     const bool small = d.C <= 32 && d.C % 32 != 16;

@@ -44,6 +44,15 @@ __global__ __launch_bounds__(WAVES * 64, MINW) void pw_kernel(const HatConvDesc 
             sct[i] = n < d.n_store ? d.r2scale[(size_t)bb * d.r2scale_bstride + n] : 0.f;
         }
     }
+    // fused LayerNorm of the finished pixel (RES variant only): gamma | beta behind the scale table
+    const bool emit_ln = RES && d.ln_out != nullptr;
+    float* lnp = sct + (scale_in_lds ? d.B * NT * 16 : 0);
+    if (emit_ln) {
+        for (int i = tid; i < NT * 16; i += nthr) {
+            lnp[i] = i < d.n_store ? d.ln_g[i] : 0.f;
+            lnp[NT * 16 + i] = i < d.n_store ? d.ln_b[i] : 0.f;
+        }
+    }
     __syncthreads();
 
     const T* xg = reinterpret_cast<const T*>(d.x);
@@ -120,29 +129,76 @@ __global__ __launch_bounds__(WAVES * 64, MINW) void pw_kernel(const HatConvDesc 
                 }
             }
         }
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) {  // finish the values in place (the LayerNorm below needs the whole pixel)
+            f32x4 v = acc[nt] + bias[nt];
+            if (d.act == HAT_ACT_GELU) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) v[r] = gelu_erf(v[r]);
+            } else if (d.act == HAT_ACT_LRELU) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) v[r] = v[r] >= 0.f ? v[r] : 0.01f * v[r];
+            }
+            if constexpr (RES) {
+                if (has_r1) v += r1v[nt];
+                if (has_r2) {
+                    const int n = min(nbase + nt * 16 + 4 * g, d.n_store - 4);
+                    const f32x4 sc = scale_in_lds ? *reinterpret_cast<const f32x4*>(sct + bidx * (NT * 16) + nt * 16 + 4 * g)
+                                                  : *reinterpret_cast<const f32x4*>(d.r2scale + bidx * d.r2scale_bstride + n);
+                    v += sc * Vec4<T>::cvt(r2v[nt]);
+                }
+            }
+            acc[nt] = v;
+        }
         if (p < npix_total) {
 #pragma unroll
             for (int nt = 0; nt < NT; ++nt) {
                 const int n = nbase + nt * 16 + 4 * g;
                 if (n < d.n_store) {
-                    f32x4 v = acc[nt] + bias[nt];
-                    if (d.act == HAT_ACT_GELU) {
+                    if (d.out_mode == HAT_O_NHWC_T) Vec4<T>::store(reinterpret_cast<T*>(d.out) + p * d.ldo + n, acc[nt]);
+                    else *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(d.out) + p * d.ldo + n) = acc[nt];
+                }
+            }
+        }
+        if constexpr (RES) {
+            if (emit_ln) {  // wave-uniform; the four lane groups of a pixel hold its NT*16 channels
+                const int C = d.n_store;
+                float sm = 0.f;
 #pragma unroll
-                        for (int r = 0; r < 4; ++r) v[r] = gelu_erf(v[r]);
-                    } else if (d.act == HAT_ACT_LRELU) {
+                for (int nt = 0; nt < NT; ++nt) {
+                    if (nt * 16 + 4 * g >= C) acc[nt] = f32x4{0.f, 0.f, 0.f, 0.f};
+                    sm += (acc[nt][0] + acc[nt][1]) + (acc[nt][2] + acc[nt][3]);
+                }
+                sm += __shfl_xor(sm, 16); sm += __shfl_xor(sm, 32);
+                const float mean = sm / (float)C;
+                float qq = 0.f;
 #pragma unroll
-                        for (int r = 0; r < 4; ++r) v[r] = v[r] >= 0.f ? v[r] : 0.01f * v[r];
+                for (int nt = 0; nt < NT; ++nt) {
+                    if (nt * 16 + 4 * g < C) {
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) { const float dl = acc[nt][r] - mean; qq += dl * dl; }
                     }
-                    if constexpr (RES) {
-                        if (has_r1) v += r1v[nt];
-                        if (has_r2) {
-                            const f32x4 sc = scale_in_lds ? *reinterpret_cast<const f32x4*>(sct + bidx * (NT * 16) + nt * 16 + 4 * g)
-                                                          : *reinterpret_cast<const f32x4*>(d.r2scale + bidx * d.r2scale_bstride + n);
-                            v += sc * Vec4<T>::cvt(r2v[nt]);
+                }
+                qq += __shfl_xor(qq, 16); qq += __shfl_xor(qq, 32);
+                const float rstd = 1.0f / sqrtf(qq / (float)C + 1e-5f);
+                if (p < npix_total) {
+                    T* lo = reinterpret_cast<T*>(d.ln_out) + p * d.ld_ln;
+#pragma unroll
+                    for (int nt = 0; nt < NT; ++nt) {
+                        const int n = nt * 16 + 4 * g;
+                        if (n < C) {
+                            const f32x4 gm = *reinterpret_cast<const f32x4*>(lnp + n);
+                            const f32x4 bt = *reinterpret_cast<const f32x4*>(lnp + NT * 16 + n);
+                            f32x4 o;
+#pragma unroll
+                            for (int r = 0; r < 4; ++r) o[r] = (acc[nt][r] - mean) * rstd * gm[r] + bt[r];
+                            Vec4<T>::store(lo + n, o);
                         }
                     }
-                    if (d.out_mode == HAT_O_NHWC_T) Vec4<T>::store(reinterpret_cast<T*>(d.out) + p * d.ldo + n, v);
-                    else *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(d.out) + p * d.ldo + n) = v;
+                    if (d.ln_ones) {  // [C] = 1.0 (the consumer's bias column), zeros up to ld_ln
+                        for (int n = C + 4 * g; n < d.ld_ln; n += 16)
+                            Vec4<T>::store(lo + n, f32x4{n == C ? 1.0f : 0.f, 0.f, 0.f, 0.f});
+                    }
                 }
             }
         }
@@ -175,6 +231,11 @@ int launch_pw(const HatConvDesc& d, hipStream_t s) {
     if (d.r2 != nullptr) {
         const size_t tbl = (size_t)d.B * NT * 16 * sizeof(float);
         if (tbl <= 16384 && lds + tbl <= HAT_LDS_MAX) { scale_in_lds = 1; lds += tbl; }
+    }
+    if (d.ln_out != nullptr) {
+        if (!res) return HAT_EUNSUPPORTED;  // the fused LayerNorm lives in the residual variant (both users have r1)
+        lds += (size_t)2 * NT * 16 * sizeof(float);
+        if (lds > HAT_LDS_MAX) return HAT_EUNSUPPORTED;
     }
     int wgs_per_cu = (int)(HAT_LDS_MAX / lds);
     // waves per SIMD the register allocation is sized for: 3 workgroups x 4 waves -> 3, 2 x 4 -> 2, 1 x 8 -> 2; the
@@ -350,6 +411,7 @@ extern "C" int hat_linear(const HatConvDesc* dp, void* stream) {
     const int vec = d.dtype == HAT_BF16 ? 8 : 4;
     if (d.ldx % vec || d.Cin % 4 || (d.x0 && (d.ldx0 % vec || d.c_split % vec || d.c_split > d.Cin))) return HAT_EINVAL;
     if ((d.r1 && d.ldr1 % 4) || (d.r2 && (d.ldr2 % 4 || !d.r2scale))) return HAT_EINVAL;
+    if (d.ln_out && (!d.ln_g || !d.ln_b || d.n_slices != 1 || d.ld_ln % 4 || d.ld_ln < d.n_store + (d.ln_ones ? 4 : 0))) return HAT_EINVAL;
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     const int ks = (d.Cin + 31) / 32;
 #define HAT_PW_CASE(TT)                                                   \

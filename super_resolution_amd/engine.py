@@ -205,7 +205,7 @@ class HATEngine:
         f = torch.float32
         w = {
             "f0": z(B, N, C, dtype=f), "tA": z(B, N, C, dtype=f), "tB": z(B, N, C, dtype=f), "tC": z(B, N, C, dtype=f),
-            "n": z(B, N, _r8(C)), "c1": z(B, N, _r8(mid)), "c2": z(B, N, _r8(C)),
+            "n": z(B, N, _r8(C)), "c1": z(B, N, _r8(mid)), "c2": z(B, N, _r8(C)), "m2": z(B, N, ops.ffn_m_ld(C)),
             "y16": z(B, N, 16), "u": z(B, N, _r8(max(hid2, 2 * C))), "g": z(B, N, _r8(max(hid2 // 2, 2 * C))),
             "q": z(B, N, _r8(C)), "kv": z(B, N, _r8(2 * C)), "ao": z(B, N, _r8(C)),
             "fb": z(B, N, 64),
@@ -291,15 +291,21 @@ class HATEngine:
                               float(cfg["conv_scale"]), w["eca_tmp"], w["scale"], B=B, C_=C)
                 self._esc_lk(esc, w, w["n"], B, H, W, nblk)
                 # t = t + aggr(cat(y16, n[pdim:])) + conv_scale * eca * c2                :236
+                # hat_linear can emit LayerNorm2 of its result as hat_ffn's m_in, turning the FFN's stage 0 into a copy.
+                # Measured at 720p HAT-S: FFN -0.034 ms, aggr +0.070 ms per block (320 more bytes per pixel to write, and
+                # the FFN's stage 0 was already hidden behind its other workgroup) — a net loss, so it stays off here.
+                pre_ln = False and "ffn" in hb and esc.aggr.frag
+                lnkw = dict(ln=hb["n2"], ln_out=w["m2"], ld_ln=w["m2"].shape[2], ln_ones=True) if pre_ln else {}
                 self._run_lin(esc.aggr, w["n"], tB, **geo, ldx=ldc, ldo=C, out_mode=O_NHWC_F32, x0=w["y16"], c_split=esc.pdim,
-                         ldx0=16, r1=t, ldr1=C, r2=w["c2"], ldr2=ldc, r2scale=w["scale"], r2scale_bstride=hb["cab2"].npad)
+                         ldx0=16, r1=t, ldr1=C, r2=w["c2"], ldr2=ldc, r2scale=w["scale"], r2scale_bstride=hb["cab2"].npad, **lnkw)
                 if "ffn" in hb:  # fused LN2 + fc1 + dw3x3 + gate + fc2 + residual (+ the next block's LayerNorm)
                     if i + 1 < len(L["habs"]):
                         nxt, gap_c = L["habs"][i + 1]["n1"], L["habs"][i + 1]["esc"].pdim
                     else:
                         nxt, gap_c = oc["n1"], (oc["esc"].pdim if "esc" in oc else 0)
+                    mkw = dict(m_in=w["m2"], ldm_in=w["m2"].shape[2]) if pre_ln else {}
                     ops.ffn(hb["ffn"], tB, tC, hb["n2"][0], hb["n2"][1], B=B, H=H, W=W, dtype=dt, ln1=nxt, n_out=w["n"],
-                            ldn=ldc, gap_out=w["gap"], gap_c=gap_c)
+                            ldn=ldc, gap_out=w["gap"], gap_c=gap_c, **mkw)
                     t, have_n, nblk = tC, True, ops.ffn_tiles(hb["ffn"], H, W, dt)
                 else:
                     ln(tB, w["n"], hb["n2"])
@@ -323,8 +329,12 @@ class HATEngine:
             ops.ocab_attention(w["q"], w["kv"], oc["bias_rot"], w["ao"], B=B, H=H, W=W, C_=C, heads=L["heads"], ws=ws,
                                wse=self.wse, ldq=ldc, ldkv=w["kv"].shape[2], ldo=ldc, dtype=dt)
             tout = tB if t is tA else t  # never write the RHAG input buffer
-            self._run_lin(oc["proj"], w["ao"], tout, **geo, ldx=ldc, ldo=C, out_mode=O_NHWC_F32, r1=t, ldr1=C)
-            ln(tout, w["n"], oc["n2"])
+            if oc["proj"].frag:  # norm2 (:306) rides on the projection's epilogue
+                self._run_lin(oc["proj"], w["ao"], tout, **geo, ldx=ldc, ldo=C, out_mode=O_NHWC_F32, r1=t, ldr1=C,
+                              ln=oc["n2"], ln_out=w["n"], ld_ln=ldc)
+            else:
+                self._run_lin(oc["proj"], w["ao"], tout, **geo, ldx=ldc, ldo=C, out_mode=O_NHWC_F32, r1=t, ldr1=C)
+                ln(tout, w["n"], oc["n2"])
             self._run_lin(oc["mlp0"], w["n"], w["g"], **geo, ldx=ldc, ldo=w["g"].shape[2], act=ACT_GELU)
             self._run_lin(oc["mlp2"], w["g"], tout, **geo, ldx=w["g"].shape[2], ldo=C, out_mode=O_NHWC_F32, r1=tout, ldr1=C)
             # RHAG tail: conv3x3 + group residual, written over the group input             :556

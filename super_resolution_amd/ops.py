@@ -303,11 +303,18 @@ def ffn_tiles(pf: PackedFFN, H: int, W: int, dtype: int) -> int:
     return n.value
 
 
+def ffn_m_ld(C_: int) -> int:
+    """Row length (elements) of the pre-normalised input image hat_ffn's m_in expects: [LN (C) | 1.0 | zeros]."""
+    return (C_ + 1 + 31) // 32 * 32
+
+
 def ffn(pf: PackedFFN, t_in, t_out, ln_g, ln_b, *, B: int, H: int, W: int, dtype: int, ln1=None, n_out=None, ldn: int = 0,
-        gap_out=None, gap_c: int = 0):
+        gap_out=None, gap_c: int = 0, m_in=None, ldm_in: int = 0):
     lib = _lib.load()
     d = _ffn_desc(pf, B, H, W, dtype)
     d.t_in, d.t_out, d.ln_g, d.ln_b = _ptr(t_in), _ptr(t_out), _ptr(ln_g), _ptr(ln_b)
+    if m_in is not None:
+        d.m_in, d.ldm_in = _ptr(m_in), ldm_in
     d.w1f, d.b1, d.dww, d.dwb, d.w2f, d.b2 = _ptr(pf.w1f), _ptr(pf.b1), _ptr(pf.dww), _ptr(pf.dwb), _ptr(pf.w2f), _ptr(pf.b2)
     if ln1 is not None:
         d.ln1_g, d.ln1_b, d.n_out, d.ldn = _ptr(ln1[0]), _ptr(ln1[1]), _ptr(n_out), ldn
@@ -316,7 +323,9 @@ def ffn(pf: PackedFFN, t_in, t_out, ln_g, ln_b, *, B: int, H: int, W: int, dtype
     # algorithmic HBM bytes per pixel: t_in read once (fp32), t_out written (fp32), the next block's LayerNorm output
     # written (T); weights and the on-chip hidden tensor do not count
     es = 2 if dtype == HAT_BF16 else 4
-    nbytes = B * H * W * (4.0 * pf.C + 4.0 * pf.C + (es * ldn if ln1 is not None else 0))
+    # (with m_in, LayerNorm2(t_in) arrives pre-computed as T rows: it replaces the haloed fp32 read; t_in is still read
+    # once for the residual)
+    nbytes = B * H * W * (4.0 * pf.C + 4.0 * pf.C + (es * ldn if ln1 is not None else 0) + (es * ldm_in if m_in is not None else 0))
     _timed(f"ffn_kernel<{_TNAME[dtype]}>", flops, lambda: _lib.check(lib.hat_ffn(C.byref(d), _stream()), "hat_ffn"),
            nbytes=nbytes)
 
@@ -367,11 +376,16 @@ def pack_linear_weight(weight: torch.Tensor, bias: Optional[torch.Tensor], dtype
 def linear(pw: PackedConv, x: torch.Tensor, out: torch.Tensor, *, B: int, H: int, W: int, dtype: int, ldx: int, ldo: int,
            out_mode: int = O_NHWC_T, act: int = ACT_NONE, n_store: Optional[int] = None, x0: Optional[torch.Tensor] = None,
            c_split: int = 0, ldx0: int = 0, r1: Optional[torch.Tensor] = None, ldr1: int = 0, r2: Optional[torch.Tensor] = None,
-           ldr2: int = 0, r2scale: Optional[torch.Tensor] = None, r2scale_bstride: int = 0):
+           ldr2: int = 0, r2scale: Optional[torch.Tensor] = None, r2scale_bstride: int = 0, ln=None,
+           ln_out: Optional[torch.Tensor] = None, ld_ln: int = 0, ln_ones: bool = False):
+    """ln=(gamma, beta), ln_out, ld_ln: also emit LayerNorm(result) as T rows (hat_linear's fused LayerNorm; needs a
+    residual operand); ln_ones appends the [1.0, 0...] tail that hat_ffn's m_in expects."""
     lib = _lib.load()
     d = HatConvDesc()
     d.x, d.x0, d.w, d.bias, d.out = _ptr(x), _ptr(x0), _ptr(pw.w), _ptr(pw.bias), _ptr(out)
     d.r1, d.r2, d.r2scale = _ptr(r1), _ptr(r2), _ptr(r2scale)
+    if ln is not None:
+        d.ln_g, d.ln_b, d.ln_out, d.ld_ln, d.ln_ones = _ptr(ln[0]), _ptr(ln[1]), _ptr(ln_out), ld_ln, int(ln_ones)
     d.B, d.H, d.W, d.Cin, d.ldx, d.x_mode = B, H, W, pw.cin, ldx, X_NHWC_T
     d.c_split, d.ldx0, d.ksize, d.Kpad, d.nt, d.n_slices = c_split, ldx0, 1, pw.kpad, pw.nt, pw.n_slices
     d.n_store = pw.nout if n_store is None else n_store

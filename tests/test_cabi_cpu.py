@@ -41,19 +41,21 @@ def test_library_exports_every_declared_symbol(lib_path):
     assert loaded.hat_layernorm_blocks() > 0
 
 
-def test_conv_desc_layout_matches_c(lib_path, tmp_path):
+@pytest.mark.parametrize("name", ["HatConvDesc", "HatFfnDesc"])
+def test_desc_layout_matches_c(lib_path, tmp_path, name):
     """Compile a tiny C program against the header and compare sizeof/offsetof with ctypes."""
-    from super_resolution_amd._lib import HatConvDesc
-    fields = [f[0] for f in HatConvDesc._fields_]
-    prog = '#include <stdio.h>\n#include <stddef.h>\n#include "hat_mi355x.h"\nint main(){printf("%zu", sizeof(HatConvDesc));\n'
-    prog += "".join(f'printf(" %zu", offsetof(HatConvDesc, {f}));\n' for f in fields) + "return 0;}\n"
+    from super_resolution_amd import _lib
+    S = getattr(_lib, name)
+    fields = [f[0] for f in S._fields_]
+    prog = f'#include <stdio.h>\n#include <stddef.h>\n#include "hat_mi355x.h"\nint main(){{printf("%zu", sizeof({name}));\n'
+    prog += "".join(f'printf(" %zu", offsetof({name}, {f}));\n' for f in fields) + "return 0;}\n"
     src = tmp_path / "layout.c"
     src.write_text(prog)
     exe = tmp_path / "layout"
     subprocess.run(["gcc", "-I", os.path.join(ROOT, "include"), str(src), "-o", str(exe)], check=True)
     vals = [int(v) for v in subprocess.run([str(exe)], capture_output=True, text=True, check=True).stdout.split()]
-    assert vals[0] == C.sizeof(HatConvDesc)
-    assert vals[1:] == [getattr(HatConvDesc, f).offset for f in fields]
+    assert vals[0] == C.sizeof(S)
+    assert vals[1:] == [getattr(S, f).offset for f in fields]
 
 
 def test_rejects_bad_arguments_without_gpu(lib_path):

@@ -395,6 +395,20 @@ def test_fused_ffn(dtype, geom):
     ops.ffn(pf, tin, tout2, dv("n2.weight"), dv("n2.bias"), B=B, H=H, W=W, dtype=dt)
     torch.cuda.synchronize()
     assert torch.equal(tout, tout2)
+    # LayerNorm2 supplied by the producer (m_in): rows [LN | 1.0 | zeros], as hat_linear's ln_ones epilogue writes them
+    ldm = ops.ffn_m_ld(C)
+    m = torch.zeros(B, H * W, ldm, dtype=tdt, device=dev)
+    m[:, :, :C] = O._ln(t.double(), sdd, "n2").to(tdt).to(dev)
+    m[:, :, C] = 1.0
+    tout3 = torch.zeros_like(tin)
+    ops.ffn(pf, tin, tout3, dv("n2.weight"), dv("n2.bias"), B=B, H=H, W=W, dtype=dt, m_in=m, ldm_in=ldm)
+    torch.cuda.synchronize()
+    if dtype == "f32":
+        check(tout3, ref, dtype, "fused ffn (m_in)", f32_tol=3e-5)
+    else:
+        upd = tout3.double().cpu() - t.double()
+        rel = float((upd - upd_ref).norm() / upd_ref.norm())
+        assert rel <= 1.5e-2, f"fused ffn (m_in) update rel err {rel:.3e}"
 
 
 # ------------------------------------------------------------------------------------------------
@@ -441,6 +455,24 @@ def test_linear_streaming(case, dtype):
                r2scale_bstride=pw.npad)
     torch.cuda.synchronize()
     check(rd.reshape(B, H, W, Cout), ref2, dtype, name + " residual epilogue", f32_tol=3e-5)
+    if pw.n_slices == 1:
+        # the same launch with the consumer's LayerNorm fused behind it, with and without hat_ffn's [1, 0...] tail
+        g_, b_ = 1 + rnd(name + "lg", (Cout,), std=0.1), rnd(name + "lb", (Cout,), std=0.1)
+        ref_ln = F.layer_norm(ref2, (Cout,), g_.double(), b_.double(), 1e-5)
+        for ones in (False, True):
+            ld_ln = ops.ffn_m_ld(Cout) if ones else ldo
+            rd2 = r1.reshape(B, H * W, Cout).to(dev).contiguous()
+            lno = torch.full((B, H * W, ld_ln), 7.0, dtype=tdt, device=dev)
+            ops.linear(pw, xd, rd2, B=B, H=H, W=W, dtype=dt, ldx=ldx, ldo=Cout, out_mode=ops.O_NHWC_F32,
+                       x0=to_dev(x0, c_split, tdt, dev), c_split=c_split, ldx0=c_split, r1=rd2, ldr1=Cout,
+                       r2=to_dev(r2, ldo, tdt, dev), ldr2=ldo, r2scale=scd, r2scale_bstride=pw.npad,
+                       ln=(g_.to(dev), b_.to(dev)), ln_out=lno, ld_ln=ld_ln, ln_ones=ones)
+            torch.cuda.synchronize()
+            assert torch.equal(rd2, rd), "the fused LayerNorm must not change the main output"
+            check(lno[:, :, :Cout].float().reshape(B, H, W, Cout), ref_ln, dtype, name + " fused LayerNorm", f32_tol=5e-5)
+            if ones:
+                tail = lno[:, :, Cout:].float().cpu()
+                assert torch.all(tail[:, :, 0] == 1.0) and torch.all(tail[:, :, 1:] == 0.0), "bias column / zero tail"
 
 
 @pytest.mark.parametrize("dtype", DT)
