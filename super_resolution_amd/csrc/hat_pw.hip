@@ -33,11 +33,11 @@ __global__ __launch_bounds__(WAVES * 64, MINW) void pw_kernel(const HatConvDesc 
     const T* wg = reinterpret_cast<const T*>(d.w) + (size_t)slice * NT * ks_total * 512;  // 512 elements per fragment
     for (int i = tid; i < NT * ks_total * 64 * (int)sizeof(T) / 2; i += nthr)  // 16 bytes per item
         *reinterpret_cast<u32x4*>(smem + (size_t)i * 16) = *reinterpret_cast<const u32x4*>(reinterpret_cast<const char*>(wg) + (size_t)i * 16);
-    f32x4 bias[NT];
-#pragma unroll
-    for (int nt = 0; nt < NT; ++nt) bias[nt] = *reinterpret_cast<const f32x4*>(d.bias + nbase + nt * 16 + 4 * g);
-    // r2's per-(batch, channel) scale: a [B][NT*16] table in LDS behind the weights (when the launcher found room)
-    float* sct = reinterpret_cast<float*>(smem + (size_t)NT * KS * 64 * 8 * sizeof(T));
+    // bias: [NT*16] fp32 in LDS right behind the weights (read per tile in the epilogue: NT*4 fewer live registers)
+    float* bsl = reinterpret_cast<float*>(smem + (size_t)NT * KS * 64 * 8 * sizeof(T));
+    for (int i = tid; i < NT * 16; i += nthr) bsl[i] = d.bias[nbase + i];
+    // r2's per-(batch, channel) scale: a [B][NT*16] table in LDS behind that (when the launcher found room)
+    float* sct = bsl + NT * 16;
     if (RES && scale_in_lds) {
         for (int i = tid; i < d.B * NT * 16; i += nthr) {
             const int bb = i / (NT * 16), n = nbase + (i - bb * NT * 16);
@@ -92,10 +92,11 @@ __global__ __launch_bounds__(WAVES * 64, MINW) void pw_kernel(const HatConvDesc 
 
     const long stride = (long)gridDim.x * nwaves;
     long tile = (long)blockIdx.x * nwaves + wave;
+    // B operands run one tile ahead of their MFMAs (two ahead measured no better); unconditional loads: load_b clamps
     frag_t bcur[KSMAX], bnxt[KSMAX];
-    if (tile < tiles) load_b(tile, bcur);
+    load_b(tile, bcur);
     for (; tile < tiles; tile += stride) {
-        if (tile + stride < tiles) load_b(tile + stride, bnxt);
+        load_b(tile + stride, bnxt);
         // Residual operands of THIS tile, all issued before the MFMAs: the compiler must assume `out` aliases r1 / r2,
         // so loads placed between the stores below are serialised one memory round trip at a time.
         const long p = tile * 16 + c16;
@@ -131,7 +132,7 @@ __global__ __launch_bounds__(WAVES * 64, MINW) void pw_kernel(const HatConvDesc 
         }
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) {  // finish the values in place (the LayerNorm below needs the whole pixel)
-            f32x4 v = acc[nt] + bias[nt];
+            f32x4 v = acc[nt] + *reinterpret_cast<const f32x4*>(bsl + nt * 16 + 4 * g);
             if (d.act == HAT_ACT_GELU) {
 #pragma unroll
                 for (int r = 0; r < 4; ++r) v[r] = gelu_erf(v[r]);
@@ -224,7 +225,7 @@ int launch_pw_cfg(const HatConvDesc& d, hipStream_t s, size_t lds, int wgs_per_c
 
 template <typename T, int NT, int KS>
 int launch_pw(const HatConvDesc& d, hipStream_t s) {
-    size_t lds = (size_t)NT * KS * 64 * 8 * sizeof(T);  // a fragment is 64 lanes x 8 elements
+    size_t lds = (size_t)NT * KS * 64 * 8 * sizeof(T) + (size_t)NT * 16 * sizeof(float);  // fragments (64 lanes x 8) + bias
     if (lds > HAT_LDS_MAX) return HAT_EUNSUPPORTED;
     const bool res = d.r1 != nullptr || d.r2 != nullptr;
     int scale_in_lds = 0;
@@ -416,6 +417,7 @@ extern "C" int hat_linear(const HatConvDesc* dp, void* stream) {
     const int ks = (d.Cin + 31) / 32;
 #define HAT_PW_CASE(TT)                                                   \
     if (d.nt == 9 && ks == 5) return launch_pw<TT, 9, 5>(d, s);           \
+    if (d.nt == 18 && ks == 5) return launch_pw<TT, 18, 5>(d, s);         \
     if (d.nt == 9 && ks == 9) return launch_pw<TT, 9, 9>(d, s);           \
     if (d.nt == 12 && ks == 6) return launch_pw<TT, 12, 6>(d, s);         \
     if (d.nt == 12 && ks == 12) return launch_pw<TT, 12, 12>(d, s);       \

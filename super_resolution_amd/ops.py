@@ -333,11 +333,20 @@ def ffn(pf: PackedFFN, t_in, t_out, ln_g, ln_b, *, B: int, H: int, W: int, dtype
 # ------------------------------------------------------------------------------------------------
 # pointwise linear layers (hat_linear): fragment-packed weights, weight-stationary streaming GEMM
 # ------------------------------------------------------------------------------------------------
-_PW_SHAPES = {(9, 5), (9, 9), (12, 6), (12, 12), (4, 1), (4, 2)}  # (nt, ceil(Cin/32)) instantiated in hat_pw.hip
+_PW_SHAPES = {(9, 5), (18, 5), (9, 9), (12, 6), (12, 12), (4, 1), (4, 2)}  # (nt, ceil(Cin/32)) instantiated in hat_pw.hip
+
+
+def choose_nt_linear(nout: int, cin: int, dtype: int):
+    """hat_linear's n-tiling: like choose_nt, except that a 288-wide output over 144 inputs (OCAB kv and MLP fc1 of the
+    embed_dim-144 models) is ONE slice of 18 n-tiles in bf16 (90 KB of weights in LDS): every slice re-reads the input,
+    and these layers are HBM-bound."""
+    if nout == 288 and -(-cin // 32) == 5 and dtype == HAT_BF16:
+        return 18, 1
+    return choose_nt(nout)
 
 
 def linear_supported(nout: int, cin: int, dtype: int) -> bool:
-    nt, _ = choose_nt(nout)
+    nt, _ = choose_nt_linear(nout, cin, dtype)
     ks = -(-cin // 32)
     lds = nt * ks * 64 * 8 * (2 if dtype == HAT_BF16 else 4)
     return (nt, ks) in _PW_SHAPES and lds <= 163840 and cin % 4 == 0
@@ -357,7 +366,7 @@ def pack_linear_weight(weight: torch.Tensor, bias: Optional[torch.Tensor], dtype
     w = w.reshape(w.shape[0], -1) * scale
     o, i = w.shape
     b = (torch.zeros(o) if bias is None else bias.detach().to(torch.float32).cpu()) * scale
-    nt, n_slices = choose_nt(o)
+    nt, n_slices = choose_nt_linear(o, i, dtype) if ksize == 1 else choose_nt(o)
     ks = -(-i // 32)
     npad = nt * 16 * n_slices
     wp = torch.zeros(npad, ks * 32)
