@@ -273,7 +273,7 @@ __global__ __launch_bounds__(WAVES * 64) void conv_kernel(const HatConvDesc d) {
                     f32x4 v = acc[nt][pt] + biasv[i];
                     if (d.act == HAT_ACT_GELU) {
 #pragma unroll
-                        for (int r = 0; r < 4; ++r) v[r] = gelu_erf(v[r]);
+                        for (int r = 0; r < 4; ++r) v[r] = gelu_act<T>(v[r]);
                     } else if (d.act == HAT_ACT_LRELU) {
 #pragma unroll
                         for (int r = 0; r < 4; ++r) v[r] = v[r] >= 0.f ? v[r] : 0.01f * v[r];

@@ -135,7 +135,7 @@ __global__ __launch_bounds__(WAVES * 64, MINW) void pw_kernel(const HatConvDesc 
             f32x4 v = acc[nt] + *reinterpret_cast<const f32x4*>(bsl + nt * 16 + 4 * g);
             if (d.act == HAT_ACT_GELU) {
 #pragma unroll
-                for (int r = 0; r < 4; ++r) v[r] = gelu_erf(v[r]);
+                for (int r = 0; r < 4; ++r) v[r] = gelu_act<T>(v[r]);
             } else if (d.act == HAT_ACT_LRELU) {
 #pragma unroll
                 for (int r = 0; r < 4; ++r) v[r] = v[r] >= 0.f ? v[r] : 0.01f * v[r];
@@ -329,7 +329,7 @@ __global__ __launch_bounds__(WAVES * 64, MINW) void tap3_kernel(const HatConvDes
                     f32x4 v = acc[nt] + bias[nt];
                     if (d.act == HAT_ACT_GELU) {
 #pragma unroll
-                        for (int r = 0; r < 4; ++r) v[r] = gelu_erf(v[r]);
+                        for (int r = 0; r < 4; ++r) v[r] = gelu_act<T>(v[r]);
                     } else if (d.act == HAT_ACT_LRELU) {
 #pragma unroll
                         for (int r = 0; r < 4; ++r) v[r] = v[r] >= 0.f ? v[r] : 0.01f * v[r];
