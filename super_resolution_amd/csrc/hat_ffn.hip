@@ -319,7 +319,6 @@ __global__ __launch_bounds__(WAVES * 64, MINW) void ffn_kernel(const HatFfnDesc 
 #pragma unroll
             for (int i = 0; i < NPTW; ++i) {
                 if (i + 1 < NPTW) load_b(i + 1, bnxt);  // next tile's operands are in flight during these MFMAs
-                __builtin_amdgcn_sched_barrier(0);      // (hipcc sinks the reads to 1-2 MFMAs before their use otherwise)
                 f32x4 acc[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
 #pragma unroll
                 for (int ks = 0; ks < ((DBG & 2) ? 0 : KS); ++ks) {
@@ -354,10 +353,10 @@ __global__ __launch_bounds__(WAVES * 64, MINW) void ffn_kernel(const HatFfnDesc 
         };
         if constexpr (DBG & 4) load_a2();
         if constexpr (!(DBG & 4)) {
-            // 20 steps (tap pair, channel group), two MFMAs each (the wave's two rows); operands AHEAD steps ahead
-            // (an LDS read takes ~8 MFMA times), pinned there: hipcc otherwise sinks each read to one MFMA before
-            // its use and every step stalls on it
-            constexpr int NSTEP = NPAIR * 4, AHEAD = BF ? 3 : 2, DEPTH = AHEAD + 1;
+            // 20 steps (tap pair, channel group), two MFMAs each (the wave's two rows); operands two steps ahead.
+            // (Pinning the reads further ahead with sched_barrier measured no faster — the other wave on the SIMD
+            // already covers the LDS latency — and cost 84 bytes/lane of scratch.)
+            constexpr int NSTEP = NPAIR * 4, AHEAD = 2, DEPTH = AHEAD + 1;
             frag_t ub[DEPTH][2];
             auto issue = [&](int st) {
                 ub[st % DEPTH][0] = ldu(st >> 2, 0, st & 3);
@@ -369,7 +368,6 @@ __global__ __launch_bounds__(WAVES * 64, MINW) void ffn_kernel(const HatFfnDesc 
             for (int st = 0; st < NSTEP; ++st) {
                 if (st + AHEAD < NSTEP) issue(st + AHEAD);
                 if (st == NSTEP / 2) load_a2();
-                __builtin_amdgcn_sched_barrier(0);
                 const int pr = st >> 2, gi = st & 3;
                 // A = [diag(w_tap0) | diag(w_tap1)]: this lane's row (channel c16 of the group) has ONE non-zero
                 // element, at position jstar of its 8-wide k group (the host zeroes the weight in lanes whose k
