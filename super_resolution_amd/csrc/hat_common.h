@@ -116,12 +116,16 @@ template <> struct Vec4<bf16_t> {
     }
 };
 
-// LDS row stride (in elements) for rows of `n` elements of size `es`: a multiple of 16 bytes with
-// an ODD number of 16-byte slots, so 16 consecutive rows read at one k offset by ds_read_b128
-// spread over all 64 banks (cdna guide §2 / Guideline 4).
+// LDS row stride (in elements) for rows of `n` elements of size `es`, for MFMA operand images read by ds_read_b128
+// with lane (c16, g) -> row base + c16, 16-byte slot k0 + g (bf16) or k0 + 2g (+1) (f32).  The instruction is serviced
+// in the lane groups {0-3,12-15,20-27}, {4-11,16-19,28-31}, {32-35,...}: rows 0-3 and 12-15 of lane group g together
+// with rows 4-11 of lane group g^1.  Enumerating all base alignments (tools: DESIGN.md 4.1): with 2-byte elements a
+// stride of S slots is conflict-free exactly when S % 4 == 2 (odd strides, the textbook padding, are 2-way on every
+// read); with 4-byte elements nothing beats an odd stride (2-way).
 __host__ __device__ constexpr int lds_row_elems(int n, int es) {
     int slots = (n * es + 15) / 16;
-    if ((slots & 1) == 0) slots += 1;
+    if (es == 2) slots += (6 - slots % 4) % 4;    // -> slots % 4 == 2
+    else if ((slots & 1) == 0) slots += 1;
     return slots * 16 / es;
 }
 
