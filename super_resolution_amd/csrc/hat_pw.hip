@@ -16,6 +16,10 @@
 
 namespace {
 
+template <bool SPEC_, bool R1_, bool R2_, bool OUTF32_, bool LN_> struct PwTag {
+    static constexpr bool spec = SPEC_, r1 = R1_, r2 = R2_, outf32 = OUTF32_, ln = LN_;
+};
+
 // RES: the launch has residual operands (r1 and/or r2): their loads are batched ahead of the MFMAs (+54 registers)
 template <typename T, int NT, int KS, int WAVES, int MINW, bool RES>
 __global__ __launch_bounds__(WAVES * 64, MINW) void pw_kernel(const HatConvDesc d, long npix_total, int tiles, int scale_in_lds) {
@@ -91,120 +95,161 @@ __global__ __launch_bounds__(WAVES * 64, MINW) void pw_kernel(const HatConvDesc 
     };
 
     const long stride = (long)gridDim.x * nwaves;
-    long tile = (long)blockIdx.x * nwaves + wave;
-    // B operands run one tile ahead of their MFMAs (two ahead measured no better); unconditional loads: load_b clamps
-    frag_t bcur[KSMAX], bnxt[KSMAX];
-    load_b(tile, bcur);
-    for (; tile < tiles; tile += stride) {
-        load_b(tile + stride, bnxt);
-        // Residual operands of THIS tile, all issued before the MFMAs: the compiler must assume `out` aliases r1 / r2,
-        // so loads placed between the stores below are serialised one memory round trip at a time.
-        const long p = tile * 16 + c16;
-        const long pc = p < npix_total ? p : npix_total - 1;
-        const long bidx = pc / ((long)d.H * d.W);
-        const bool has_r1 = RES && d.r1 != nullptr, has_r2 = RES && d.r2 != nullptr;
+    const long tile0 = (long)blockIdx.x * nwaves + wave;
+
+    // The tile loop exists in several copies selected ONCE per launch.  A specialised copy (Tag::spec) has no control
+    // flow around its memory operations — operand presence, output type and "every channel is stored" are compile-time,
+    // lanes past the last pixel recompute and re-store the last pixel — because hipcc merges its s_waitcnt bookkeeping
+    // conservatively at every CFG join: with conditional loads/stores in the body each wait became vmcnt(0), i.e. the
+    // prefetch of the next tile and the stores of the previous one were drained on every tile.
+    auto tile_loop = [&](auto tag) {
+        using Tag = decltype(tag);
+        constexpr bool SPEC = Tag::spec;
+        const bool has_r1 = SPEC ? Tag::r1 : (RES && d.r1 != nullptr);
+        const bool has_r2 = SPEC ? Tag::r2 : (RES && d.r2 != nullptr);
+        const bool out_f32 = SPEC ? Tag::outf32 : (d.out_mode != HAT_O_NHWC_T);
+        const bool do_ln = SPEC ? Tag::ln : emit_ln;
+        const bool sc_lds = SPEC ? true : (scale_in_lds != 0);
+        long tile = tile0;
+        // Software pipeline, ordered around how hipcc places its waits.  Its s_waitcnt bookkeeping is merged at the loop
+        // header with the (store-free) loop entry state, so every in-loop wait on a load degenerates to "wait for
+        // everything issued so far"; the loop therefore issues its loads LAST (B operands of the tile after next, residual
+        // operands of the next tile) and consumes them only after the next tile's MFMAs: by then they, and the stores
+        // issued just before them, have had a whole MFMA phase to complete.
+        auto load_r = [&](long t, f32x4 (&r1v)[RES ? NT : 1], typename Vec4<T>::raw_t (&r2v)[RES ? NT : 1]) {
+            if constexpr (RES) {
+                long pp = t * 16 + c16;
+                pp = pp < npix_total ? pp : npix_total - 1;
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt) {
+                    const int n = SPEC ? nt * 16 + 4 * g : min(nbase + nt * 16 + 4 * g, d.n_store - 4);
+                    if (has_r1) r1v[nt] = *reinterpret_cast<const f32x4*>(d.r1 + pp * d.ldr1 + n);
+                    if (has_r2) r2v[nt] = Vec4<T>::load_raw(reinterpret_cast<const T*>(d.r2) + pp * d.ldr2 + n);
+                }
+            }
+        };
+        frag_t bcur[KSMAX], bnxt[KSMAX];
         f32x4 r1v[RES ? NT : 1];
         typename Vec4<T>::raw_t r2v[RES ? NT : 1];
-        if constexpr (RES) {
+        load_b(tile, bcur);
+        load_b(tile + stride, bnxt);
+        load_r(tile, r1v, r2v);
+        for (; tile < tiles; tile += stride) {
+            const long p = tile * 16 + c16;
+            const long pc = p < npix_total ? p : npix_total - 1;
+            const long bidx = pc / ((long)d.H * d.W);
+            f32x4 acc[NT];
 #pragma unroll
-            for (int nt = 0; nt < NT; ++nt) {
-                const int n = min(nbase + nt * 16 + 4 * g, d.n_store - 4);
-                if (has_r1) r1v[nt] = *reinterpret_cast<const f32x4*>(d.r1 + pc * d.ldr1 + n);
-                if (has_r2) r2v[nt] = Vec4<T>::load_raw(reinterpret_cast<const T*>(d.r2) + pc * d.ldr2 + n);
-            }
-        }
-        f32x4 acc[NT];
+            for (int nt = 0; nt < NT; ++nt) acc[nt] = f32x4{0.f, 0.f, 0.f, 0.f};
+            // The weight fragments are re-read from LDS for every tile: make the address opaque per iteration, or the
+            // compiler hoists all NT*KS loop-invariant fragments into registers and spills.
+            int wofs = lane * 8;
+            asm volatile("" : "+v"(wofs));
 #pragma unroll
-        for (int nt = 0; nt < NT; ++nt) acc[nt] = f32x4{0.f, 0.f, 0.f, 0.f};
-        // The weight fragments are re-read from LDS for every tile: make the address opaque per iteration, or the
-        // compiler hoists all NT*KS loop-invariant fragments into registers and spills.
-        int wofs = lane * 8;
-        asm volatile("" : "+v"(wofs));
-#pragma unroll
-        for (int ks = 0; ks < KSMAX; ++ks) {
-            if (ks < ks_total) {
-#pragma unroll
-                for (int nt = 0; nt < NT; ++nt) {
-                    const frag_t af = M::load(Wl + (size_t)(nt * ks_total + ks) * 512 + wofs);
-                    acc[nt] = M::mma(af, bcur[ks], acc[nt]);
-                }
-            }
-        }
-#pragma unroll
-        for (int nt = 0; nt < NT; ++nt) {  // finish the values in place (the LayerNorm below needs the whole pixel)
-            f32x4 v = acc[nt] + *reinterpret_cast<const f32x4*>(bsl + nt * 16 + 4 * g);
-            if (d.act == HAT_ACT_GELU) {
-#pragma unroll
-                for (int r = 0; r < 4; ++r) v[r] = gelu_act<T>(v[r]);
-            } else if (d.act == HAT_ACT_LRELU) {
-#pragma unroll
-                for (int r = 0; r < 4; ++r) v[r] = v[r] >= 0.f ? v[r] : 0.01f * v[r];
-            }
-            if constexpr (RES) {
-                if (has_r1) v += r1v[nt];
-                if (has_r2) {
-                    const int n = min(nbase + nt * 16 + 4 * g, d.n_store - 4);
-                    const f32x4 sc = scale_in_lds ? *reinterpret_cast<const f32x4*>(sct + bidx * (NT * 16) + nt * 16 + 4 * g)
-                                                  : *reinterpret_cast<const f32x4*>(d.r2scale + bidx * d.r2scale_bstride + n);
-                    v += sc * Vec4<T>::cvt(r2v[nt]);
-                }
-            }
-            acc[nt] = v;
-        }
-        if (p < npix_total) {
-#pragma unroll
-            for (int nt = 0; nt < NT; ++nt) {
-                const int n = nbase + nt * 16 + 4 * g;
-                if (n < d.n_store) {
-                    if (d.out_mode == HAT_O_NHWC_T) Vec4<T>::store(reinterpret_cast<T*>(d.out) + p * d.ldo + n, acc[nt]);
-                    else *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(d.out) + p * d.ldo + n) = acc[nt];
-                }
-            }
-        }
-        if constexpr (RES) {
-            if (emit_ln) {  // wave-uniform; the four lane groups of a pixel hold its NT*16 channels
-                const int C = d.n_store;
-                float sm = 0.f;
-#pragma unroll
-                for (int nt = 0; nt < NT; ++nt) {
-                    if (nt * 16 + 4 * g >= C) acc[nt] = f32x4{0.f, 0.f, 0.f, 0.f};
-                    sm += (acc[nt][0] + acc[nt][1]) + (acc[nt][2] + acc[nt][3]);
-                }
-                sm += __shfl_xor(sm, 16); sm += __shfl_xor(sm, 32);
-                const float mean = sm / (float)C;
-                float qq = 0.f;
-#pragma unroll
-                for (int nt = 0; nt < NT; ++nt) {
-                    if (nt * 16 + 4 * g < C) {
-#pragma unroll
-                        for (int r = 0; r < 4; ++r) { const float dl = acc[nt][r] - mean; qq += dl * dl; }
-                    }
-                }
-                qq += __shfl_xor(qq, 16); qq += __shfl_xor(qq, 32);
-                const float rstd = 1.0f / sqrtf(qq / (float)C + 1e-5f);
-                if (p < npix_total) {
-                    T* lo = reinterpret_cast<T*>(d.ln_out) + p * d.ld_ln;
+            for (int ks = 0; ks < KSMAX; ++ks) {
+                if (ks < ks_total) {
 #pragma unroll
                     for (int nt = 0; nt < NT; ++nt) {
-                        const int n = nt * 16 + 4 * g;
-                        if (n < C) {
-                            const f32x4 gm = *reinterpret_cast<const f32x4*>(lnp + n);
-                            const f32x4 bt = *reinterpret_cast<const f32x4*>(lnp + NT * 16 + n);
-                            f32x4 o;
-#pragma unroll
-                            for (int r = 0; r < 4; ++r) o[r] = (acc[nt][r] - mean) * rstd * gm[r] + bt[r];
-                            Vec4<T>::store(lo + n, o);
-                        }
-                    }
-                    if (d.ln_ones) {  // [C] = 1.0 (the consumer's bias column), zeros up to ld_ln
-                        for (int n = C + 4 * g; n < d.ld_ln; n += 16)
-                            Vec4<T>::store(lo + n, f32x4{n == C ? 1.0f : 0.f, 0.f, 0.f, 0.f});
+                        const frag_t af = M::load(Wl + (size_t)(nt * ks_total + ks) * 512 + wofs);
+                        acc[nt] = M::mma(af, bcur[ks], acc[nt]);
                     }
                 }
             }
-        }
 #pragma unroll
-        for (int ks = 0; ks < KSMAX; ++ks) bcur[ks] = bnxt[ks];
+            for (int nt = 0; nt < NT; ++nt) {  // finish the values in place (the LayerNorm below needs the whole pixel)
+                f32x4 v = acc[nt] + *reinterpret_cast<const f32x4*>(bsl + nt * 16 + 4 * g);
+                if (d.act == HAT_ACT_GELU) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) v[r] = gelu_act<T>(v[r]);
+                } else if (d.act == HAT_ACT_LRELU) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) v[r] = v[r] >= 0.f ? v[r] : 0.01f * v[r];
+                }
+                if constexpr (RES) {
+                    if (has_r1) v += r1v[nt];
+                    if (has_r2) {
+                        const int n = min(nbase + nt * 16 + 4 * g, d.n_store - 4);
+                        const f32x4 sc = sc_lds ? *reinterpret_cast<const f32x4*>(sct + bidx * (NT * 16) + nt * 16 + 4 * g)
+                                                : *reinterpret_cast<const f32x4*>(d.r2scale + bidx * d.r2scale_bstride + n);
+                        v += sc * Vec4<T>::cvt(r2v[nt]);
+                    }
+                }
+                acc[nt] = v;
+            }
+#pragma unroll
+            for (int ks = 0; ks < KSMAX; ++ks) bcur[ks] = bnxt[ks];   // (the next tile's operands have arrived)
+            if (SPEC || p < npix_total) {
+                const long ps = SPEC ? pc : p;
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt) {
+                    const int n = nbase + nt * 16 + 4 * g;
+                    if (SPEC || n < d.n_store) {
+                        if (!out_f32) Vec4<T>::store(reinterpret_cast<T*>(d.out) + ps * d.ldo + n, acc[nt]);
+                        else *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(d.out) + ps * d.ldo + n) = acc[nt];
+                    }
+                }
+            }
+            if constexpr (RES) {
+                if (do_ln) {  // wave-uniform; the four lane groups of a pixel hold its NT*16 channels
+                    const int C = d.n_store;
+                    float sm = 0.f;
+#pragma unroll
+                    for (int nt = 0; nt < NT; ++nt) {
+                        if (!SPEC && nt * 16 + 4 * g >= C) acc[nt] = f32x4{0.f, 0.f, 0.f, 0.f};
+                        sm += (acc[nt][0] + acc[nt][1]) + (acc[nt][2] + acc[nt][3]);
+                    }
+                    sm += __shfl_xor(sm, 16); sm += __shfl_xor(sm, 32);
+                    const float mean = sm / (float)C;
+                    float qq = 0.f;
+#pragma unroll
+                    for (int nt = 0; nt < NT; ++nt) {
+                        if (SPEC || nt * 16 + 4 * g < C) {
+#pragma unroll
+                            for (int r = 0; r < 4; ++r) { const float dl = acc[nt][r] - mean; qq += dl * dl; }
+                        }
+                    }
+                    qq += __shfl_xor(qq, 16); qq += __shfl_xor(qq, 32);
+                    const float rstd = 1.0f / sqrtf(qq / (float)C + 1e-5f);
+                    if (SPEC || p < npix_total) {
+                        T* lo = reinterpret_cast<T*>(d.ln_out) + (SPEC ? pc : p) * d.ld_ln;
+#pragma unroll
+                        for (int nt = 0; nt < NT; ++nt) {
+                            const int n = nt * 16 + 4 * g;
+                            if (SPEC || n < C) {
+                                const f32x4 gm = *reinterpret_cast<const f32x4*>(lnp + n);
+                                const f32x4 bt = *reinterpret_cast<const f32x4*>(lnp + NT * 16 + n);
+                                f32x4 o;
+#pragma unroll
+                                for (int r = 0; r < 4; ++r) o[r] = (acc[nt][r] - mean) * rstd * gm[r] + bt[r];
+                                Vec4<T>::store(lo + n, o);
+                            }
+                        }
+                        if constexpr (!SPEC) {
+                            if (d.ln_ones) {  // [C] = 1.0 (the consumer's bias column), zeros up to ld_ln
+                                for (int n = C + 4 * g; n < d.ld_ln; n += 16)
+                                    Vec4<T>::store(lo + n, f32x4{n == C ? 1.0f : 0.f, 0.f, 0.f, 0.f});
+                            }
+                        }
+                    }
+                }
+            }
+            load_b(tile + 2 * stride, bnxt);
+            load_r(tile + stride, r1v, r2v);
+        }
+    };
+
+    // specialised copies need: one slice that stores all NT*16 channels, no split source oddities beyond load_b's, and
+    // (with r2) the scale table in LDS
+    const bool full = d.n_slices == 1 && d.n_store == NT * 16;
+    if constexpr (RES) {
+        const bool f32o = d.out_mode == HAT_O_NHWC_F32;
+        if (full && f32o && d.r1 && d.r2 && scale_in_lds && !emit_ln) tile_loop(PwTag<true, true, true, true, false>{});
+        else if (full && f32o && d.r1 && !d.r2 && emit_ln && !d.ln_ones) tile_loop(PwTag<true, true, false, true, true>{});
+        else if (full && f32o && d.r1 && !d.r2 && !emit_ln) tile_loop(PwTag<true, true, false, true, false>{});
+        else tile_loop(PwTag<false, false, false, false, false>{});
+    } else {
+        if (full && d.out_mode == HAT_O_NHWC_T) tile_loop(PwTag<true, false, false, false, false>{});
+        else tile_loop(PwTag<false, false, false, false, false>{});
     }
 }
 
