@@ -128,11 +128,14 @@ __global__ __launch_bounds__(WAVES * 64, MINW) void pw_kernel(const HatConvDesc 
                 }
             }
         };
-        frag_t bcur[KSMAX], bnxt[KSMAX];
+        // (without residual registers and with a short K there is room for a third set: B operands two tiles ahead)
+        constexpr bool DEEP = !RES && KS <= 5;
+        frag_t bcur[KSMAX], bnxt[KSMAX], bnx2[DEEP ? KSMAX : 1];
         f32x4 r1v[RES ? NT : 1];
         typename Vec4<T>::raw_t r2v[RES ? NT : 1];
         load_b(tile, bcur);
         load_b(tile + stride, bnxt);
+        if constexpr (DEEP) load_b(tile + 2 * stride, bnx2);
         load_r(tile, r1v, r2v);
         for (; tile < tiles; tile += stride) {
             const long p = tile * 16 + c16;
@@ -177,7 +180,10 @@ __global__ __launch_bounds__(WAVES * 64, MINW) void pw_kernel(const HatConvDesc 
                 acc[nt] = v;
             }
 #pragma unroll
-            for (int ks = 0; ks < KSMAX; ++ks) bcur[ks] = bnxt[ks];   // (the next tile's operands have arrived)
+            for (int ks = 0; ks < KSMAX; ++ks) {   // (the next tile's operands have arrived)
+                bcur[ks] = bnxt[ks];
+                if constexpr (DEEP) bnxt[ks] = bnx2[ks];
+            }
             if (SPEC || p < npix_total) {
                 const long ps = SPEC ? pc : p;
 #pragma unroll
@@ -233,7 +239,8 @@ __global__ __launch_bounds__(WAVES * 64, MINW) void pw_kernel(const HatConvDesc 
                     }
                 }
             }
-            load_b(tile + 2 * stride, bnxt);
+            if constexpr (DEEP) load_b(tile + 3 * stride, bnx2);
+            else load_b(tile + 2 * stride, bnxt);
             load_r(tile + stride, r1v, r2v);
         }
     };
