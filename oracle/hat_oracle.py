@@ -416,6 +416,34 @@ def psnr_y(img_rgb_u8, img2_rgb_u8, crop_border: int) -> float:
     return float("inf") if mse == 0 else 10.0 * math.log10(255.0 * 255.0 / mse)
 
 
+def ssim_y(img_rgb_u8, img2_rgb_u8, crop_border: int) -> float:
+    """calculate_ssim(test_y_channel=True): metrics/psnr_ssim.py:86-125 with _ssim :170-198 — an 11x11 Gaussian window
+    (sigma 1.5, cv2.getGaussianKernel) correlated in VALID mode (filter2D(...)[5:-5, 5:-5]), c1 = (0.01*255)^2,
+    c2 = (0.03*255)^2, mean of the SSIM map.  Independent of the product code: full 2-D window via scipy."""
+    import numpy as np
+    from scipy.signal import correlate2d
+
+    def to_y(a):
+        a = a.astype(np.float32) / np.float32(255.0)
+        y = np.dot(a, [65.481, 128.553, 24.966]) + 16.0
+        return ((y / 255.0).astype(np.float32) * np.float32(255.0)).astype(np.float64)
+
+    a, b2 = to_y(img_rgb_u8), to_y(img2_rgb_u8)
+    if crop_border:
+        a = a[crop_border:-crop_border, crop_border:-crop_border]
+        b2 = b2[crop_border:-crop_border, crop_border:-crop_border]
+    x = np.arange(11) - 5.0
+    k = np.exp(-(x ** 2) / (2 * 1.5 ** 2))
+    k /= k.sum()
+    win = np.outer(k, k)
+    f = lambda z: correlate2d(z, win, mode="valid")
+    c1, c2 = (0.01 * 255) ** 2, (0.03 * 255) ** 2
+    mu1, mu2 = f(a), f(b2)
+    s1, s2, s12 = f(a * a) - mu1 ** 2, f(b2 * b2) - mu2 ** 2, f(a * b2) - mu1 * mu2
+    m = ((2 * mu1 * mu2 + c1) * (2 * s12 + c2)) / ((mu1 ** 2 + mu2 ** 2 + c1) * (s1 + s2 + c2))
+    return float(m.mean())
+
+
 def psnr_float(a: Tensor, b: Tensor, peak: float = 1.0) -> float:
     mse = float(((a.double() - b.double()) ** 2).mean())
     return float("inf") if mse == 0 else 10.0 * math.log10(peak * peak / mse)

@@ -1,0 +1,62 @@
+"""SURVEY §8 f1 on the GPU: `python -m super_resolution_amd.test -opt x.yml` (YAML options, PNG folders, checkpoint
+file, tile mode, PSNR/SSIM) through the MI355X path, against the oracle driven through its own harness restatement."""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+import yaml
+
+from oracle import hat_oracle as O
+from super_resolution_amd import data as D, metrics as M, synth
+
+pytestmark = pytest.mark.gpu
+
+NET = dict(type="HAT", upscale=2, in_chans=3, img_size=32, window_size=16, compress_ratio=4, squeeze_factor=4,
+           conv_scale=0.01, overlap_ratio=0.5, img_range=1.0, depths=[2], embed_dim=24, num_heads=[2], mlp_ratio=2,
+           upsampler="pixelshuffle", resi_connection="1conv")
+
+
+@pytest.mark.parametrize("tile", [None, {"tile_size": 32, "tile_pad": 16}], ids=["whole", "tiled"])
+def test_cli_end_to_end(tmp_path, tile):
+    if not torch.cuda.is_available():
+        pytest.skip("needs an MI355X")
+    from super_resolution_amd import test as T
+    cfg = O.make_cfg(**{k: v for k, v in NET.items() if k != "type"})
+    sd = synth.synth_state_dict(O.blank_state_dict(cfg), 21)
+    ckpt = tmp_path / "net.pth"
+    torch.save({"params_ema": {"module." + k: v for k, v in sd.items()}}, ckpt)  # EMA key + DataParallel prefix (base_model.py:302-315)
+    for i, (h, w) in enumerate([(45, 38), (32, 64)]):
+        D.write_image(M.tensor2img(synth.synth_input(30 + i, (1, 3, h, w))), str(tmp_path / "lq" / f"im{i}.png"))
+        D.write_image(M.tensor2img(synth.synth_input(40 + i, (1, 3, 2 * h, 2 * w))), str(tmp_path / "gt" / f"im{i}.png"))
+    opt = {"name": "toy", "model_type": "HATModel", "scale": 2, "num_gpu": 1,
+           "datasets": {"test_1": {"name": "Toy", "type": "PairedImageDataset", "dataroot_gt": str(tmp_path / "gt"),
+                                   "dataroot_lq": str(tmp_path / "lq"), "io_backend": {"type": "disk"}}},
+           "network_g": dict(NET, compute_dtype="f32"),
+           "path": {"pretrain_network_g": str(ckpt), "strict_load_g": True, "param_key_g": "params_ema",
+                    "visualization": str(tmp_path / "vis")},
+           "val": {"save_img": True, "suffix": None, "metrics": {
+               "psnr": {"type": "calculate_psnr", "crop_border": 2, "test_y_channel": True},
+               "ssim": {"type": "calculate_ssim", "crop_border": 2, "test_y_channel": True}}}}
+    if tile:
+        opt["tile"] = tile
+    yml = tmp_path / "opt.yml"
+    yml.write_text(yaml.safe_dump(opt))
+    res = T.main(["-opt", str(yml)])
+    net = lambda x: O.hat_forward(x, sd, cfg)
+    psnrs = []
+    for i in range(2):
+        lq8 = D.read_image(str(tmp_path / "lq" / f"im{i}.png")).unsqueeze(0)
+        img, ph, pw = O.pre_process(lq8, 16)
+        ref = O.tile_process(img, net, 2, tile["tile_size"], tile["tile_pad"]) if tile else net(img)
+        ref8 = O.tensor2img_rgb(O.post_process(ref, ph, pw, 2))
+        from PIL import Image
+        saved = np.asarray(Image.open(str(tmp_path / "vis" / "Toy" / f"im{i}_toy.png")).convert("RGB"))
+        assert saved.shape == ref8.shape
+        diff = np.abs(saved.astype(int) - ref8.astype(int))
+        assert diff.max() <= 1 and (diff != 0).mean() < 1e-3, "fp32 path: at most isolated +-1 rounding flips"
+        gt8 = M.tensor2img(D.read_image(str(tmp_path / "gt" / f"im{i}.png")))
+        psnrs.append(O.psnr_y(ref8, gt8, 2))
+        assert res["Toy"]["images"][i]["psnr"] == pytest.approx(psnrs[-1], abs=1e-3)  # north_star: within 1e-3 dB
+    assert res["Toy"]["mean"]["psnr"] == pytest.approx(float(np.mean(psnrs)), abs=1e-3)
