@@ -76,6 +76,32 @@ def test_cfg1_hats_x2_64_vs_reference_golden(dtype):
 
 
 @pytest.mark.parametrize("dtype", ["f32", "bf16"])
+@pytest.mark.parametrize("case", [("HAT-S_x4", "summary_HAT-S_x4_256.npz"), ("HAT-S_x4", "summary_HAT-S_x4_64.npz"),
+                                  ("HAT-L_x4", "summary_HAT-L_x4_128.npz")], ids=["cfg2_HAT-S_256", "HAT-S_64", "HAT-L_128"])
+def test_full_models_vs_reference_summaries(case, dtype):
+    """The full shipped variants (36 / 72 HABs) at BASELINE config 2 (HAT-S x4, 3x256x256) and HAT-L x4 3x128x128 against
+    the reference's own outputs: three crops (corners + centre) and the global mean / std / abs-sum checksums that
+    gen_golden.py recorded (the whole tensors are too large to commit)."""
+    name, fn = case
+    dev = _dev()
+    g = golden(fn)
+    net = build_net(name, dtype, dev)
+    y = net(synth.synth_input(X_SEED, tuple(int(v) for v in g["x_shape"])).to(dev))
+    torch.cuda.synchronize()
+    y = y.detach().float().cpu()
+    assert torch.isfinite(y).all()
+    for k in ("tl", "br", "ce"):
+        ref = torch.as_tensor(g["crop_" + k])
+        a, b, c = (int(v) for v in g["pos_" + k])
+        assert_close(y[..., a:a + c, b:b + c], ref, dtype, f"{name}/{dtype} crop {k} vs reference")
+    tol = 2e-5 if dtype == "f32" else 2e-3
+    yd = y.double()
+    assert abs(float(yd.mean()) - float(g["mean"])) <= tol, "global mean"
+    assert abs(float(yd.std()) - float(g["std"])) <= tol * 2, "global std"
+    assert abs(float(yd.abs().sum()) - float(g["abs_sum"])) <= tol * y.numel(), "global abs-sum"
+
+
+@pytest.mark.parametrize("dtype", ["f32", "bf16"])
 def test_batch_and_rectangular_vs_oracle(dtype):
     """B=2 (per-sample dynamic kernels) on a non-square frame, against the CPU oracle."""
     dev = _dev()
