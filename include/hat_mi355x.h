@@ -115,6 +115,41 @@ int hat_conv3x3_small_groups(const HatConvDesc* d, int32_t* groups_out);
 int hat_conv3x3_small(const HatConvDesc* d, void* stream);
 
 /*
+ * CAB expand conv + ECA folded into the ESC aggregation (hat_arch.py:84-90, 66-78, 233-236 with esc_arch.py:123) for
+ * models whose CAB squeeze width is <= 8 channels (HAT-S: 6).  The reference computes
+ *     c2 = conv3x3(c1) + b2;  e = sigmoid(conv1d_k(mean_pixels(c2)));  x = t + aggr(y) + conv_scale * e * c2.
+ * mean_pixels(c2) is linear in c1, so it follows from the column sums of c1 and its border rows / columns
+ * (zero padding: tap (dy,dx) misses one border row and/or column), BEFORE c2 exists:
+ *   hat_cab_fold:  scale = conv_scale * e,  wf = fragment-packed (scale * W2) with K = tap*8 + ci,
+ *                  bias_out = bias_in + scale * b2            (tiny per-sample kernel)
+ *   hat_aggr_cab:  out = r1 + W_aggr . x + wf . im2col3x3(c1) + bias_out   — c2 never exists in memory.
+ */
+typedef struct HatCabFoldDesc {
+    const void* c1;          /* (B,H,W,ld1) T: GELU(conv3x3(n)), `mid` channels, pad channels zero, ld1 == 8 */
+    const float* c1_colsum;  /* [B][tiles][ldcs]: per-tile column sums of c1 as hat_conv's colsum emits them */
+    const float* w2;         /* [C][mid][3][3] fp32 */
+    const float* b2;         /* [C] */
+    const float* wk;         /* ECA conv1d weights [k] */
+    const float* bias_in;    /* [C]: the aggregation bias */
+    float* scale;            /* out [B][ld_scale] */
+    void* wf;                /* out [B][nt][3][64][8] T, nt = ceil(C/16) */
+    float* bias_out;         /* out [B][nt*16] */
+    float* tmp;              /* scratch [B][32][ldcs] */
+    int32_t B, H, W, C, mid, ld1, tiles, ldcs, k, ld_scale, dtype;
+    float conv_scale;
+} HatCabFoldDesc;
+int hat_cab_fold(const HatCabFoldDesc* d, void* stream);
+
+typedef struct HatAggrCabDesc {
+    HatConvDesc lin;         /* the aggregation as for hat_linear: x (+x0 / c_split), w (fragment packed, nt = 9, Cin = 144),
+                                out (fp32, HAT_O_NHWC_F32), r1 (fp32); bias, r2*, ln_* are ignored */
+    const void* c1;          /* (B,H,W,8) T */
+    const void* wf;          /* hat_cab_fold's wf */
+    const float* bias_b;     /* hat_cab_fold's bias_out, [B][nt*16] */
+} HatAggrCabDesc;
+int hat_aggr_cab(const HatAggrCabDesc* d, void* stream);
+
+/*
  * LayerNorm over the channel dimension (eps 1e-5, affine), fp32 in -> T or fp32 out
  * (nn.LayerNorm at hat_arch.py:209,214,291,306,743 and PatchEmbed.norm :573-574).
  * Optionally emits per-block partial sums of the first `gap_c` output channels

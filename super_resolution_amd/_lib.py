@@ -57,6 +57,22 @@ class HatFfnDesc(C.Structure):
     ]
 
 
+class HatCabFoldDesc(C.Structure):
+    """Mirror of `struct HatCabFoldDesc` (include/hat_mi355x.h)."""
+    _fields_ = [
+        ("c1", C.c_void_p), ("c1_colsum", C.c_void_p), ("w2", C.c_void_p), ("b2", C.c_void_p), ("wk", C.c_void_p),
+        ("bias_in", C.c_void_p), ("scale", C.c_void_p), ("wf", C.c_void_p), ("bias_out", C.c_void_p), ("tmp", C.c_void_p),
+        ("B", C.c_int32), ("H", C.c_int32), ("W", C.c_int32), ("C", C.c_int32), ("mid", C.c_int32), ("ld1", C.c_int32),
+        ("tiles", C.c_int32), ("ldcs", C.c_int32), ("k", C.c_int32), ("ld_scale", C.c_int32), ("dtype", C.c_int32),
+        ("conv_scale", C.c_float),
+    ]
+
+
+class HatAggrCabDesc(C.Structure):
+    """Mirror of `struct HatAggrCabDesc` (include/hat_mi355x.h)."""
+    _fields_ = [("lin", HatConvDesc), ("c1", C.c_void_p), ("wf", C.c_void_p), ("bias_b", C.c_void_p)]
+
+
 # name -> (restype, argtypes); every symbol declared in include/hat_mi355x.h
 SIGNATURES = {
     "hat_abi_version": (C.c_int, []),
@@ -68,6 +84,8 @@ SIGNATURES = {
     "hat_linear": (C.c_int, [C.POINTER(HatConvDesc), C.c_void_p]),
     "hat_conv3x3_small_groups": (C.c_int, [C.POINTER(HatConvDesc), C.POINTER(C.c_int32)]),
     "hat_conv3x3_small": (C.c_int, [C.POINTER(HatConvDesc), C.c_void_p]),
+    "hat_cab_fold": (C.c_int, [C.POINTER(HatCabFoldDesc), C.c_void_p]),
+    "hat_aggr_cab": (C.c_int, [C.POINTER(HatAggrCabDesc), C.c_void_p]),
     "hat_ffn_tiles": (C.c_int, [C.POINTER(HatFfnDesc), C.POINTER(C.c_int32)]),
     "hat_ffn": (C.c_int, [C.POINTER(HatFfnDesc), C.c_void_p]),
     "hat_layernorm_blocks": (C.c_int, []),

@@ -213,6 +213,90 @@ __global__ __launch_bounds__(256) void eca_scale_kernel(const float* __restrict_
 }
 
 // ---------------------------------------------------------------------------------------------
+// hat_cab_fold (see include/hat_mi355x.h): one 256-thread workgroup per sample.
+// ---------------------------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(256) void cab_fold_kernel(const HatCabFoldDesc d) {
+    __shared__ float red[256 * 8];
+    __shared__ float bord[4][8];     // first row, last row, first column, last column sums
+    __shared__ float S[9][8];        // per-tap sums of c1 over the output pixels the tap contributes to
+    __shared__ float mean[256];
+    __shared__ float scl[256];
+    const int tid = threadIdx.x, b = blockIdx.x;
+    const int H = d.H, W = d.W, C = d.C, mid = d.mid;
+    const T* c1 = reinterpret_cast<const T*>(d.c1) + (size_t)b * H * W * d.ld1;
+    // border sums, fixed order: each thread strides a line, then a tree over the 256 partials
+    for (int line = 0; line < 4; ++line) {
+        const int len = line < 2 ? W : H;
+        float a[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        for (int i = tid; i < len; i += 256) {
+            const size_t pix = line == 0 ? (size_t)i : line == 1 ? (size_t)(H - 1) * W + i : line == 2 ? (size_t)i * W : (size_t)i * W + (W - 1);
+#pragma unroll
+            for (int c = 0; c < 8; ++c) a[c] += to_f(c1[pix * d.ld1 + c]);
+        }
+#pragma unroll
+        for (int c = 0; c < 8; ++c) red[tid * 8 + c] = a[c];
+        __syncthreads();
+        for (int st = 128; st > 0; st >>= 1) {
+            if (tid < st) {
+#pragma unroll
+                for (int c = 0; c < 8; ++c) red[tid * 8 + c] += red[(tid + st) * 8 + c];
+            }
+            __syncthreads();
+        }
+        if (tid < 8) bord[line][tid] = red[tid];
+        __syncthreads();
+    }
+    if (tid < 72) {
+        const int tap = tid >> 3, c = tid & 7;
+        const int dy = tap / 3 - 1, dx = tap % 3 - 1;
+        float tot = 0.f;
+        for (int p = 0; p < 32; ++p) tot += d.tmp[((size_t)b * 32 + p) * d.ldcs + c];
+        // input pixel q = p + (dy,dx) must lie inside: dy=+1 never reads row 0, dy=-1 never reads row H-1 (same for columns)
+        float v = tot;
+        const int rl = dy == 1 ? 0 : dy == -1 ? 1 : -1, cl = dx == 1 ? 2 : dx == -1 ? 3 : -1;
+        if (rl >= 0) v -= bord[rl][c];
+        if (cl >= 0) v -= bord[cl][c];
+        if (rl >= 0 && cl >= 0) {
+            const size_t pix = (size_t)(rl == 0 ? 0 : H - 1) * W + (cl == 2 ? 0 : W - 1);
+            v += to_f(c1[pix * d.ld1 + c]);
+        }
+        S[tap][c] = c < mid ? v : 0.f;
+    }
+    __syncthreads();
+    float m = 0.f;
+    if (tid < C) {
+        for (int ci = 0; ci < mid; ++ci)
+            for (int tap = 0; tap < 9; ++tap) m += d.w2[((size_t)tid * mid + ci) * 9 + tap] * S[tap][ci];
+        m = m / ((float)H * (float)W) + d.b2[tid];
+    }
+    mean[tid] = m;
+    __syncthreads();
+    float sc = 0.f;
+    if (tid < C) {
+        float e = 0.f;
+        for (int j = 0; j < d.k; ++j) {
+            const int cc = tid + j - d.k / 2;
+            if (cc >= 0 && cc < C) e += d.wk[j] * mean[cc];
+        }
+        sc = d.conv_scale / (1.0f + expf(-e));
+        d.scale[(size_t)b * d.ld_scale + tid] = sc;
+    }
+    scl[tid] = sc;
+    __syncthreads();
+    const int nt = (C + 15) / 16;
+    for (int n = tid; n < nt * 16; n += 256) d.bias_out[(size_t)b * nt * 16 + n] = n < C ? d.bias_in[n] + scl[n] * d.b2[n] : 0.f;
+    T* wf = reinterpret_cast<T*>(d.wf) + (size_t)b * nt * 3 * 512;
+    for (int i = tid; i < nt * 3 * 512; i += 256) {
+        const int j = i & 7, lane = (i >> 3) & 63, ks = (i >> 9) % 3, t = i / (3 * 512);
+        const int co = t * 16 + (lane & 15), k = 32 * ks + 8 * (lane >> 4) + j;
+        const int tap = k >> 3, ci = k & 7;
+        const float v = (co < C && tap < 9 && ci < mid) ? scl[co] * d.w2[((size_t)co * mid + ci) * 9 + tap] : 0.f;
+        wf[i] = to_T<T>(v);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
 // depthwise 3x3 + bias on 2*hid channels, then a * silu(g).  4 channels per thread.
 // ---------------------------------------------------------------------------------------------
 template <typename T>
@@ -292,6 +376,23 @@ extern "C" int hat_eca_scale(const float* colsum, int32_t tiles, int32_t ldc, in
     int rc = hat_check_launch();
     if (rc) return rc;
     HAT_LAUNCH(eca_scale_kernel, dim3(B), dim3(256), 0, s, tmp, ldc, 1.0f / (float)npix, wk, k, conv_scale, scale, C);
+    return hat_check_launch();
+}
+
+extern "C" int hat_cab_fold(const HatCabFoldDesc* dp, void* stream) {
+    if (!dp) return HAT_EINVAL;
+    const HatCabFoldDesc& d = *dp;
+    if (!d.c1 || !d.c1_colsum || !d.w2 || !d.b2 || !d.wk || !d.bias_in || !d.scale || !d.wf || !d.bias_out || !d.tmp) return HAT_EINVAL;
+    if (d.B < 1 || d.H < 2 || d.W < 2 || d.C < 1 || d.C > 256 || d.mid < 1 || d.mid > 8 || d.ld1 != 8 || d.tiles < 1 || d.ldcs < 8 ||
+        d.ldcs > 256 || d.k < 1 || (d.k & 1) == 0 || d.ld_scale < d.C)
+        return HAT_EINVAL;
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    HAT_LAUNCH(eca_reduce_kernel, dim3(32, d.B), dim3(256), 0, s, d.c1_colsum, d.tiles, d.ldcs, d.tmp);
+    int rc = hat_check_launch();
+    if (rc) return rc;
+    if (d.dtype == HAT_BF16) HAT_LAUNCH(cab_fold_kernel<bf16_t>, dim3(d.B), dim3(256), 0, s, d);
+    else if (d.dtype == HAT_F32) HAT_LAUNCH(cab_fold_kernel<float>, dim3(d.B), dim3(256), 0, s, d);
+    else return HAT_EINVAL;
     return hat_check_launch();
 }
 

@@ -482,6 +482,103 @@ extern "C" int hat_linear(const HatConvDesc* dp, void* stream) {
     return HAT_EUNSUPPORTED;  // shapes not instantiated here: use hat_conv (ksize 1)
 }
 
+// ---------------------------------------------------------------------------------------------------------
+// hat_aggr_cab (include/hat_mi355x.h): the ESC aggregation 1x1 with the CAB expand conv folded in as three more
+// k-steps whose B operands are the 3x3 neighbours of c1 (8 channels = 16 bytes per tap, gathered like tap3_kernel)
+// and whose A operands are the per-sample (ECA-scaled) expand weights.  Same streaming structure and software
+// pipeline as pw_kernel's specialised loop; one grid row per sample (the folded weights are per sample).
+// ---------------------------------------------------------------------------------------------------------
+namespace {
+template <typename T>
+__global__ __launch_bounds__(256, 2) void aggr_cab_kernel(const HatAggrCabDesc dd, int tiles) {
+    using M = MT<T>;
+    using frag_t = typename M::frag_t;
+    constexpr int NT = 9, KS = 5, KC = 3, KT = KS + KC, nthr = 256, WAVES = 4;
+    const HatConvDesc& d = dd.lin;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    T* Wl = reinterpret_cast<T*>(smem);                       // [NT][KS][64][8] aggregation weights
+    T* Wc = Wl + (size_t)NT * KS * 512;                       // [NT][KC][64][8] this sample's folded expand weights
+    float* bsl = reinterpret_cast<float*>(Wc + (size_t)NT * KC * 512);
+    const int tid = threadIdx.x, lane = tid & 63, g = lane >> 4, c16 = lane & 15, wave = tid >> 6;
+    const int b = blockIdx.y;
+    {
+        const char* w1 = reinterpret_cast<const char*>(d.w);
+        const char* w2 = reinterpret_cast<const char*>(dd.wf) + (size_t)b * NT * KC * 512 * sizeof(T);
+        for (int i = tid; i < NT * KS * 512 * (int)sizeof(T) / 16; i += nthr)
+            *reinterpret_cast<u32x4*>(smem + (size_t)i * 16) = *reinterpret_cast<const u32x4*>(w1 + (size_t)i * 16);
+        for (int i = tid; i < NT * KC * 512 * (int)sizeof(T) / 16; i += nthr)
+            *reinterpret_cast<u32x4*>(reinterpret_cast<char*>(Wc) + (size_t)i * 16) = *reinterpret_cast<const u32x4*>(w2 + (size_t)i * 16);
+        for (int i = tid; i < NT * 16; i += nthr) bsl[i] = dd.bias_b[(size_t)b * NT * 16 + i];
+    }
+    __syncthreads();
+    const int H = d.H, W = d.W, Cin = d.Cin;
+    const long HW = (long)H * W;
+    const T* xg = reinterpret_cast<const T*>(d.x) + (size_t)b * HW * d.ldx;
+    const T* xg0 = d.x0 ? reinterpret_cast<const T*>(d.x0) + (size_t)b * HW * d.ldx0 : nullptr;
+    const T* c1 = reinterpret_cast<const T*>(dd.c1) + (size_t)b * HW * 8;
+    const T* zero = reinterpret_cast<const T*>(hat_zero_page);
+    const float* r1 = d.r1 + (size_t)b * HW * d.ldr1;
+    float* out = reinterpret_cast<float*>(d.out) + (size_t)b * HW * d.ldo;
+
+    auto load_b = [&](long t, frag_t (&bf)[KT]) {
+        long p = t * 16 + c16;
+        p = p < HW ? p : HW - 1;
+        const int y = (int)(p / W), x = (int)(p - (long)y * W);
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+            const int c = min(ks * 32 + 8 * g, ((Cin + 7) & ~7) - 8);
+            bf[ks] = M::load((xg0 != nullptr && c < d.c_split) ? xg0 + p * d.ldx0 + c : xg + p * d.ldx + c);
+        }
+#pragma unroll
+        for (int kc = 0; kc < KC; ++kc) {
+            const int tap = 4 * kc + g;
+            const int dy = tap / 3 - 1, dx = tap - (tap / 3) * 3 - 1;
+            const int yy = y + dy, xx = x + dx;
+            const bool inb = tap < 9 && yy >= 0 && yy < H && xx >= 0 && xx < W;
+            bf[KS + kc] = M::load(inb ? c1 + ((size_t)yy * W + xx) * 8 : zero);
+        }
+    };
+    auto load_r = [&](long t, f32x4 (&rv)[NT]) {
+        long p = t * 16 + c16;
+        p = p < HW ? p : HW - 1;
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) rv[nt] = *reinterpret_cast<const f32x4*>(r1 + p * d.ldr1 + nt * 16 + 4 * g);
+    };
+    const long stride = (long)gridDim.x * WAVES;
+    long tile = (long)blockIdx.x * WAVES + wave;
+    frag_t bcur[KT], bnxt[KT];
+    f32x4 rv[NT];
+    load_b(tile, bcur);
+    load_b(tile + stride, bnxt);
+    load_r(tile, rv);
+    for (; tile < tiles; tile += stride) {
+        long p = tile * 16 + c16;
+        p = p < HW ? p : HW - 1;   // lanes past the last pixel recompute and re-store it
+        f32x4 acc[NT];
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) acc[nt] = f32x4{0.f, 0.f, 0.f, 0.f};
+        int wofs = lane * 8;
+        asm volatile("" : "+v"(wofs));
+#pragma unroll
+        for (int ks = 0; ks < KT; ++ks) {
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) {
+                const T* wp = ks < KS ? Wl + (size_t)(nt * KS + ks) * 512 : Wc + (size_t)(nt * KC + (ks - KS)) * 512;
+                acc[nt] = M::mma(M::load(wp + wofs), bcur[ks], acc[nt]);
+            }
+        }
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) acc[nt] += *reinterpret_cast<const f32x4*>(bsl + nt * 16 + 4 * g) + rv[nt];
+#pragma unroll
+        for (int ks = 0; ks < KT; ++ks) bcur[ks] = bnxt[ks];
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) *reinterpret_cast<f32x4*>(out + p * d.ldo + nt * 16 + 4 * g) = acc[nt];
+        load_b(tile + 2 * stride, bnxt);
+        load_r(tile + stride, rv);
+    }
+}
+}  // namespace
+
 /* 3x3 convolution with the whole weight slice resident in LDS (see tap3_kernel); weights fragment packed like
  * hat_linear with K index = tap * Cin_p + ci.  colsum (optional) is [B][groups][nt*16] with groups from
  * hat_conv3x3_small_groups().  HAT_EUNSUPPORTED for shapes that are not instantiated: use hat_conv. */
@@ -497,4 +594,27 @@ extern "C" int hat_conv3x3_small(const HatConvDesc* dp, void* stream) {
     const int vec = d.dtype == HAT_BF16 ? 8 : 4;
     if (d.ldx % vec || d.n_store % 4 || d.ldo % 4 || d.n_store > d.nt * 16) return HAT_EINVAL;
     return tap3_dispatch(d, reinterpret_cast<hipStream_t>(stream), nullptr);
+}
+
+extern "C" int hat_aggr_cab(const HatAggrCabDesc* dp, void* stream) {
+    if (!dp) return HAT_EINVAL;
+    const HatConvDesc& d = dp->lin;
+    if (!d.x || !d.w || !d.out || !d.r1 || !dp->c1 || !dp->wf || !dp->bias_b) return HAT_EINVAL;
+    if (d.B < 1 || d.H < 1 || d.W < 1 || d.ksize != 1 || d.x_mode != HAT_X_NHWC_T || d.out_mode != HAT_O_NHWC_F32) return HAT_EINVAL;
+    if (d.nt != 9 || d.n_slices != 1 || d.n_store != 144 || d.Cin != 144) return HAT_EUNSUPPORTED;
+    const int vec = d.dtype == HAT_BF16 ? 8 : 4;
+    if (d.ldx % vec || d.ldx < 144 || d.ldo % 4 || d.ldo < 144 || d.ldr1 % 4 || d.ldr1 < 144) return HAT_EINVAL;
+    if (d.x0 && (d.ldx0 % vec || d.c_split % vec || d.c_split > d.Cin)) return HAT_EINVAL;
+    if (d.dtype != HAT_BF16) return HAT_EUNSUPPORTED;  // (the fp32 image of the weights does not leave room for two workgroups)
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    const size_t lds = (size_t)9 * (5 + 3) * 512 * sizeof(bf16_t) + (size_t)9 * 16 * sizeof(float);
+    const long HW = (long)d.H * d.W;
+    const int tiles = (int)((HW + 15) / 16);
+    int gx = 512 / (d.B < 2 ? 1 : 2);
+    if (gx > (tiles + 3) / 4) gx = (tiles + 3) / 4;
+    auto kern = aggr_cab_kernel<bf16_t>;
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return (int)e;
+    HAT_LAUNCH(kern, dim3(gx, d.B, 1), dim3(256), lds, s, *dp, tiles);
+    return hat_check_launch();
 }

@@ -16,6 +16,7 @@ T = bf16 (performance path) or fp32 (exact-fp32 parity path).
 from __future__ import annotations
 
 import math
+import os
 from typing import Dict, Optional
 
 import torch
@@ -135,6 +136,12 @@ class HATEngine:
                     "eca_w": vec(p + ".conv_block.cab.3.conv.weight").reshape(-1),
                 }
                 hb["esc"].aggr = self._lin(sd, *hb["esc"].aggr_keys)
+                w2raw = sd[p + ".conv_block.cab.2.weight"]
+                # CAB expand conv + ECA folded into the aggregation (hat_cab_fold / hat_aggr_cab): squeeze width <= 8 only
+                if (hb["esc"].aggr.frag and not hb["cab0"].frag and ops.aggr_cab_supported(C, w2raw.shape[1], dt)
+                        and not os.environ.get("HAT_NO_CAB_FOLD")):
+                    hb["fold"] = {"w2": w2raw.detach().to(**f32).contiguous(), "b2": vec(p + ".conv_block.cab.2.bias"),
+                                  "ba": vec(hb["esc"].aggr_keys[1])}
                 if not self.fuse_ffn:
                     hb["fc1"] = self._lin(sd, p + ".mlp.fc1.weight", p + ".mlp.fc1.bias")
                     hb["fc2"] = self._lin(sd, p + ".mlp.fc2.weight", p + ".mlp.fc2.bias")
@@ -222,6 +229,13 @@ class HATEngine:
             tiles = ops.conv3x3_small_groups(cab2, B, H, W, self.dtype) if cab2.frag else ops.conv_tiles(cab2, H, W, self.dtype)
             w["tiles"] = tiles
             w["colsum"] = z(B, tiles, cab2.npad, dtype=f)
+        hab0 = self.layers[0]["habs"][0] if self.layers and self.layers[0]["habs"] else None
+        if hab0 is not None and "fold" in hab0:
+            cab0 = hab0["cab0"]
+            w["tiles1"] = ops.conv_tiles(cab0, H, W, self.dtype)
+            w["colsum1"] = z(B, w["tiles1"], cab0.npad, dtype=f)
+            w["wf"] = z(B, hab0["esc"].aggr.nt * 3 * 512)
+            w["bias_b"] = z(B, hab0["esc"].aggr.npad, dtype=f)
         h, wd = H, W
         w["ups"] = []
         for _, r in self.ups:
@@ -283,21 +297,35 @@ class HATEngine:
                     ln(t, w["n"], hb["n1"], gap_c=esc.pdim)
                     nblk = LNB
                 mid = hb["cab0"].nout
-                c3 = ops.conv3x3_small if hb["cab0"].frag else ops.conv
-                c3(hb["cab0"], w["n"], w["c1"], **geo, ldx=ldc, ldo=_r8(mid), act=ACT_GELU, n_store=_r4(mid))
-                c3 = ops.conv3x3_small if hb["cab2"].frag else ops.conv
-                c3(hb["cab2"], w["c1"], w["c2"], **geo, ldx=_r8(mid), ldo=ldc, colsum=w["colsum"])
-                ops.eca_scale(w["colsum"], w["tiles"], hb["cab2"].npad, N, hb["eca_w"], hb["eca_w"].numel(),
-                              float(cfg["conv_scale"]), w["eca_tmp"], w["scale"], B=B, C_=C)
-                self._esc_lk(esc, w, w["n"], B, H, W, nblk)
-                # t = t + aggr(cat(y16, n[pdim:])) + conv_scale * eca * c2                :236
-                # hat_linear can emit LayerNorm2 of its result as hat_ffn's m_in, turning the FFN's stage 0 into a copy.
-                # Measured at 720p HAT-S: FFN -0.034 ms, aggr +0.070 ms per block (320 more bytes per pixel to write, and
-                # the FFN's stage 0 was already hidden behind its other workgroup) — a net loss, so it stays off here.
-                pre_ln = False and "ffn" in hb and esc.aggr.frag
-                lnkw = dict(ln=hb["n2"], ln_out=w["m2"], ld_ln=w["m2"].shape[2], ln_ones=True) if pre_ln else {}
-                self._run_lin(esc.aggr, w["n"], tB, **geo, ldx=ldc, ldo=C, out_mode=O_NHWC_F32, x0=w["y16"], c_split=esc.pdim,
-                         ldx0=16, r1=t, ldr1=C, r2=w["c2"], ldr2=ldc, r2scale=w["scale"], r2scale_bstride=hb["cab2"].npad, **lnkw)
+                if "fold" in hb:
+                    # c2 = conv3x3(c1) never exists: its ECA pooling follows from the sums of c1 (hat_cab_fold) and the
+                    # scaled expand conv is three more k-steps of the aggregation GEMM (hat_aggr_cab)
+                    fo = hb["fold"]
+                    ops.conv(hb["cab0"], w["n"], w["c1"], **geo, ldx=ldc, ldo=8, act=ACT_GELU, n_store=8, colsum=w["colsum1"])
+                    ops.cab_fold(w["c1"], w["colsum1"], w["tiles1"], hb["cab0"].npad, fo["w2"], fo["b2"], hb["eca_w"],
+                                 hb["eca_w"].numel(), fo["ba"], float(cfg["conv_scale"]), w["scale"], w["wf"], w["bias_b"],
+                                 w["eca_tmp"], B=B, H=H, W=W, C_=C, mid=mid, dtype=dt)
+                    self._esc_lk(esc, w, w["n"], B, H, W, nblk)
+                    ops.aggr_cab(esc.aggr, w["n"], tB, w["c1"], w["wf"], w["bias_b"], **geo, ldx=ldc, ldo=C, x0=w["y16"],
+                                 c_split=esc.pdim, ldx0=16, r1=t, ldr1=C)
+                    pre_ln = False
+                else:
+                    c3 = ops.conv3x3_small if hb["cab0"].frag else ops.conv
+                    c3(hb["cab0"], w["n"], w["c1"], **geo, ldx=ldc, ldo=_r8(mid), act=ACT_GELU, n_store=_r4(mid))
+                    c3 = ops.conv3x3_small if hb["cab2"].frag else ops.conv
+                    c3(hb["cab2"], w["c1"], w["c2"], **geo, ldx=_r8(mid), ldo=ldc, colsum=w["colsum"])
+                    ops.eca_scale(w["colsum"], w["tiles"], hb["cab2"].npad, N, hb["eca_w"], hb["eca_w"].numel(),
+                                  float(cfg["conv_scale"]), w["eca_tmp"], w["scale"], B=B, C_=C)
+                    self._esc_lk(esc, w, w["n"], B, H, W, nblk)
+                    # t = t + aggr(cat(y16, n[pdim:])) + conv_scale * eca * c2                :236
+                    # hat_linear can emit LayerNorm2 of its result as hat_ffn's m_in, turning the FFN's stage 0 into a copy.
+                    # Measured at 720p HAT-S: FFN -0.034 ms, aggr +0.070 ms per block (320 more bytes per pixel to write,
+                    # and the FFN's stage 0 was already hidden behind its other workgroup) — a net loss, so it stays off.
+                    pre_ln = False and "ffn" in hb and esc.aggr.frag
+                    lnkw = dict(ln=hb["n2"], ln_out=w["m2"], ld_ln=w["m2"].shape[2], ln_ones=True) if pre_ln else {}
+                    self._run_lin(esc.aggr, w["n"], tB, **geo, ldx=ldc, ldo=C, out_mode=O_NHWC_F32, x0=w["y16"],
+                                  c_split=esc.pdim, ldx0=16, r1=t, ldr1=C, r2=w["c2"], ldr2=ldc, r2scale=w["scale"],
+                                  r2scale_bstride=hb["cab2"].npad, **lnkw)
                 if "ffn" in hb:  # fused LN2 + fc1 + dw3x3 + gate + fc2 + residual (+ the next block's LayerNorm)
                     if i + 1 < len(L["habs"]):
                         nxt, gap_c = L["habs"][i + 1]["n1"], L["habs"][i + 1]["esc"].pdim

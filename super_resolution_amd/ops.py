@@ -11,7 +11,7 @@ import torch
 
 from . import _lib
 from ._lib import (ACT_GELU, ACT_LRELU, ACT_NONE, HAT_BF16, HAT_F32, O_NCHW_F32, O_NHWC_F32, O_NHWC_T, O_PIXSHUF_T,
-                   X_NCHW_F32_MEAN, X_NHWC_F32, X_NHWC_T, HatConvDesc, HatFfnDesc)
+                   X_NCHW_F32_MEAN, X_NHWC_F32, X_NHWC_T, HatAggrCabDesc, HatCabFoldDesc, HatConvDesc, HatFfnDesc)
 
 TORCH_DTYPE = {HAT_F32: torch.float32, HAT_BF16: torch.bfloat16}
 DTYPE_CODE = {"f32": HAT_F32, "fp32": HAT_F32, "float32": HAT_F32, "bf16": HAT_BF16, "bfloat16": HAT_BF16}
@@ -441,3 +441,36 @@ def conv3x3_small(pw: PackedConv, x, out, *, B: int, H: int, W: int, dtype: int,
     _timed(f"tap3_kernel<{_TNAME[dtype]}, {pw.nt}>", flops,
            lambda: _lib.check(lib.hat_conv3x3_small(C.byref(d), _stream()), f"hat_conv3x3_small(Cin={pw.cin}, N={pw.nout})"),
            tag=f"c3s {pw.cin}->{pw.nout} {H}x{W}")
+
+
+# ------------------------------------------------------------------------------------------------
+# CAB expand conv + ECA folded into the ESC aggregation (hat_cab_fold + hat_aggr_cab)
+# ------------------------------------------------------------------------------------------------
+def aggr_cab_supported(C_: int, mid: int, dtype: int) -> bool:
+    return C_ == 144 and mid <= 8 and dtype == HAT_BF16
+
+
+def cab_fold(c1, c1_colsum, tiles: int, ldcs: int, w2, b2, wk, k: int, bias_in, conv_scale: float, scale, wf, bias_out, tmp, *,
+             B: int, H: int, W: int, C_: int, mid: int, dtype: int):
+    lib = _lib.load()
+    d = HatCabFoldDesc()
+    d.c1, d.c1_colsum, d.w2, d.b2, d.wk, d.bias_in = _ptr(c1), _ptr(c1_colsum), _ptr(w2), _ptr(b2), _ptr(wk), _ptr(bias_in)
+    d.scale, d.wf, d.bias_out, d.tmp = _ptr(scale), _ptr(wf), _ptr(bias_out), _ptr(tmp)
+    d.B, d.H, d.W, d.C, d.mid, d.ld1, d.tiles, d.ldcs, d.k, d.ld_scale, d.dtype = B, H, W, C_, mid, 8, tiles, ldcs, k, scale.shape[1], dtype
+    d.conv_scale = conv_scale
+    _timed("cab_fold", 0.0, lambda: _lib.check(lib.hat_cab_fold(C.byref(d), _stream()), "hat_cab_fold"))
+
+
+def aggr_cab(pw: PackedConv, x, out, c1, wf, bias_b, *, B: int, H: int, W: int, dtype: int, ldx: int, ldo: int, x0=None,
+             c_split: int = 0, ldx0: int = 0, r1=None, ldr1: int = 0):
+    lib = _lib.load()
+    dd = HatAggrCabDesc()
+    d = dd.lin
+    d.x, d.x0, d.w, d.bias, d.out, d.r1 = _ptr(x), _ptr(x0), _ptr(pw.w), _ptr(pw.bias), _ptr(out), _ptr(r1)
+    d.B, d.H, d.W, d.Cin, d.ldx, d.x_mode = B, H, W, pw.cin, ldx, X_NHWC_T
+    d.c_split, d.ldx0, d.ksize, d.Kpad, d.nt, d.n_slices, d.n_store = c_split, ldx0, 1, pw.kpad, pw.nt, pw.n_slices, pw.nout
+    d.ldo, d.out_mode, d.act, d.ldr1, d.dtype = ldo, O_NHWC_F32, ACT_NONE, ldr1, dtype
+    dd.c1, dd.wf, dd.bias_b = _ptr(c1), _ptr(wf), _ptr(bias_b)
+    flops = 2.0 * B * H * W * pw.nout * (pw.cin + 9 * 8)
+    _timed("aggr_cab_kernel", flops, lambda: _lib.check(lib.hat_aggr_cab(C.byref(dd), _stream()), "hat_aggr_cab"),
+           tag=f"aggr+cab {pw.cin}+72->{pw.nout} {H}x{W}")

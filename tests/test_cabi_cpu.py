@@ -41,7 +41,7 @@ def test_library_exports_every_declared_symbol(lib_path):
     assert loaded.hat_layernorm_blocks() > 0
 
 
-@pytest.mark.parametrize("name", ["HatConvDesc", "HatFfnDesc"])
+@pytest.mark.parametrize("name", ["HatConvDesc", "HatFfnDesc", "HatCabFoldDesc", "HatAggrCabDesc"])
 def test_desc_layout_matches_c(lib_path, tmp_path, name):
     """Compile a tiny C program against the header and compare sizeof/offsetof with ctypes."""
     from super_resolution_amd import _lib

@@ -502,3 +502,47 @@ def test_conv3x3_small(case, dtype):
     torch.cuda.synchronize()
     check(out[:, :, :Cout].float().reshape(B, H, W, Cout), q(ref.float(), dtype).double() if dtype == "bf16" else ref, dtype, name)
     check(colsum.sum(1)[:, :Cout] / (H * W), ref.mean((1, 2)), dtype, name + " column sums", f32_tol=3e-5)
+
+
+# ------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("geom", [(2, 24, 40), (1, 19, 27)], ids=["B2_24x40", "B1_19x27_ragged"])
+def test_aggr_with_folded_cab(geom):
+    """hat_cab_fold + hat_aggr_cab: x = t + aggr(y) + conv_scale * ECA(c2) * c2 with c2 = conv3x3(c1) + b2 never
+    materialised (hat_arch.py:84-90, 66-78, 233-236; esc_arch.py:123): the ECA pooling comes analytically from the
+    sums of c1, the scaled expand conv rides on the aggregation GEMM."""
+    B, H, W = geom
+    C, mid, dtype = 144, 6, "bf16"
+    dev, ops = _dev(), _ops()
+    dt = ops.DTYPE_CODE[dtype]
+    tdt = ops.TORCH_DTYPE[dt]
+    x = q(rnd("acx", (B, H, W, C)), dtype)
+    x0 = q(rnd("acx0", (B, H, W, 16)), dtype)
+    c1 = q(F.gelu(rnd("acc1", (B, H, W, mid))), dtype)
+    t = rnd("act", (B, H, W, C))
+    wa, ba = q(rnd("acwa", (C, C), std=C ** -0.5), dtype), rnd("acba", (C,), std=0.1)
+    w2, b2 = rnd("acw2", (C, mid, 3, 3), std=(9 * mid) ** -0.5), rnd("acb2", (C,), std=0.1)
+    wk = rnd("acwk", (5,), std=1.0)
+    conv_scale = 0.37
+    # reference in fp64
+    c2 = F.conv2d(c1.permute(0, 3, 1, 2).double(), w2.double(), b2.double(), padding=1)          # (B,C,H,W)
+    e = torch.sigmoid(F.conv1d(c2.mean((2, 3))[:, None, :], wk.double()[None, None, :], padding=2))[:, 0]  # (B,C)
+    xin = torch.cat([x0, x[..., 16:]], -1)
+    ref = t.double() + F.linear(xin.double(), wa.double(), ba.double()) + conv_scale * (e[:, :, None, None] * c2).permute(0, 2, 3, 1)
+    # device
+    pw = ops.pack_linear_weight(wa, ba, dt, dev)
+    c1d = to_dev(c1, 8, tdt, dev)
+    colsum = torch.zeros(B, 1, 16, device=dev)
+    colsum[:, 0, :8] = c1d.float().sum(1)
+    scale = torch.zeros(B, pw.npad, device=dev)
+    wf = torch.zeros(B, pw.nt * 3 * 512, dtype=tdt, device=dev)
+    bias_b = torch.zeros(B, pw.npad, device=dev)
+    tmp = torch.zeros(B, 32, 16, device=dev)
+    ops.cab_fold(c1d, colsum, 1, 16, w2.to(dev).contiguous(), b2.to(dev), wk.to(dev), 5, ba.to(dev), conv_scale, scale, wf, bias_b, tmp,
+                 B=B, H=H, W=W, C_=C, mid=mid, dtype=dt)
+    torch.cuda.synchronize()
+    check(scale[:, :C], conv_scale * e, "f32", "folded ECA scale", f32_tol=2e-6)
+    out = torch.zeros(B, H * W, C, device=dev)
+    ops.aggr_cab(pw, to_dev(x, C, tdt, dev), out, c1d, wf, bias_b, B=B, H=H, W=W, dtype=dt, ldx=C, ldo=C,
+                 x0=to_dev(x0, 16, tdt, dev), c_split=16, ldx0=16, r1=t.reshape(B, H * W, C).to(dev).contiguous(), ldr1=C)
+    torch.cuda.synchronize()
+    check(out.reshape(B, H, W, C), ref, dtype, "aggr + folded cab")
