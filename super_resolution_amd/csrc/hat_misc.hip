@@ -175,20 +175,32 @@ __global__ __launch_bounds__(1024) void esc_weights_kernel(const float* __restri
 // ---------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void eca_reduce_kernel(const float* __restrict__ colsum, int tiles, int ldc,
                                                          float* __restrict__ tmp) {
-    const int c = threadIdx.x, part = blockIdx.x, b = blockIdx.y;
-    if (c >= ldc) return;
+    // 32 parts x B workgroups; inside a part the 256 threads form nsub = 256 / pow2(ldc) interleaved sub-rows per
+    // channel (a 16-channel colsum would otherwise keep 16 lanes busy with hundreds of dependent loads), combined in
+    // a fixed order through LDS.
+    __shared__ float sub[256];
+    int lw = 1;
+    while (lw < ldc) lw <<= 1;
+    const int nsub = 256 / lw;
+    const int c = threadIdx.x % lw, sb = threadIdx.x / lw, part = blockIdx.x, b = blockIdx.y;
     const int per = (tiles + 31) / 32;
     const int t0 = part * per, t1 = min(tiles, t0 + per);
-    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
-    int t = t0;
-    for (; t + 3 < t1; t += 4) {
-        s0 += colsum[((size_t)b * tiles + t) * ldc + c];
-        s1 += colsum[((size_t)b * tiles + t + 1) * ldc + c];
-        s2 += colsum[((size_t)b * tiles + t + 2) * ldc + c];
-        s3 += colsum[((size_t)b * tiles + t + 3) * ldc + c];
+    float s0 = 0.f, s1 = 0.f;
+    if (c < ldc) {
+        int t = t0 + sb;
+        for (; t + nsub < t1; t += 2 * nsub) {
+            s0 += colsum[((size_t)b * tiles + t) * ldc + c];
+            s1 += colsum[((size_t)b * tiles + t + nsub) * ldc + c];
+        }
+        if (t < t1) s0 += colsum[((size_t)b * tiles + t) * ldc + c];
     }
-    for (; t < t1; ++t) s0 += colsum[((size_t)b * tiles + t) * ldc + c];
-    tmp[((size_t)b * 32 + part) * ldc + c] = (s0 + s1) + (s2 + s3);
+    sub[threadIdx.x] = s0 + s1;
+    __syncthreads();
+    if (sb == 0 && c < ldc) {
+        float s = 0.f;
+        for (int i = 0; i < nsub; ++i) s += sub[i * lw + c];
+        tmp[((size_t)b * 32 + part) * ldc + c] = s;
+    }
 }
 
 __global__ __launch_bounds__(256) void eca_scale_kernel(const float* __restrict__ tmp, int ldc, float inv_npix,
@@ -217,7 +229,8 @@ __global__ __launch_bounds__(256) void eca_scale_kernel(const float* __restrict_
 // ---------------------------------------------------------------------------------------------
 template <typename T>
 __global__ __launch_bounds__(256) void cab_fold_kernel(const HatCabFoldDesc d) {
-    __shared__ float red[256 * 8];
+    __shared__ float red[256 * 33];  // [thread][4 lines x 8 channels], rows padded to 33 floats
+    __shared__ float part[8][32];
     __shared__ float bord[4][8];     // first row, last row, first column, last column sums
     __shared__ float S[9][8];        // per-tap sums of c1 over the output pixels the tap contributes to
     __shared__ float mean[256];
@@ -225,26 +238,43 @@ __global__ __launch_bounds__(256) void cab_fold_kernel(const HatCabFoldDesc d) {
     const int tid = threadIdx.x, b = blockIdx.x;
     const int H = d.H, W = d.W, C = d.C, mid = d.mid;
     const T* c1 = reinterpret_cast<const T*>(d.c1) + (size_t)b * H * W * d.ld1;
-    // border sums, fixed order: each thread strides a line, then a tree over the 256 partials
-    for (int line = 0; line < 4; ++line) {
-        const int len = line < 2 ? W : H;
-        float a[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-        for (int i = tid; i < len; i += 256) {
-            const size_t pix = line == 0 ? (size_t)i : line == 1 ? (size_t)(H - 1) * W + i : line == 2 ? (size_t)i * W : (size_t)i * W + (W - 1);
+    // border sums in a fixed order: every thread strides the four lines, then two levels of partial sums
+    {
+        float a[4][8];
 #pragma unroll
-            for (int c = 0; c < 8; ++c) a[c] += to_f(c1[pix * d.ld1 + c]);
-        }
+        for (int line = 0; line < 4; ++line)
 #pragma unroll
-        for (int c = 0; c < 8; ++c) red[tid * 8 + c] = a[c];
-        __syncthreads();
-        for (int st = 128; st > 0; st >>= 1) {
-            if (tid < st) {
+            for (int c = 0; c < 8; ++c) a[line][c] = 0.f;
+        const int lmax = W > H ? W : H;
+        for (int i = tid; i < lmax; i += 256) {
 #pragma unroll
-                for (int c = 0; c < 8; ++c) red[tid * 8 + c] += red[(tid + st) * 8 + c];
+            for (int line = 0; line < 4; ++line) {
+                const int len = line < 2 ? W : H;
+                if (i < len) {
+                    const size_t pix = line == 0 ? (size_t)i : line == 1 ? (size_t)(H - 1) * W + i : line == 2 ? (size_t)i * W : (size_t)i * W + (W - 1);
+                    const typename MT<T>::frag_t v = MT<T>::load(c1 + pix * d.ld1);
+#pragma unroll
+                    for (int c = 0; c < 8; ++c) a[line][c] += to_f(v[c]);
+                }
             }
-            __syncthreads();
         }
-        if (tid < 8) bord[line][tid] = red[tid];
+#pragma unroll
+        for (int line = 0; line < 4; ++line)
+#pragma unroll
+            for (int c = 0; c < 8; ++c) red[tid * 33 + line * 8 + c] = a[line][c];
+        __syncthreads();
+        {
+            const int v = tid & 31, pt = tid >> 5;
+            float sp = 0.f;
+            for (int i = 0; i < 32; ++i) sp += red[(pt * 32 + i) * 33 + v];
+            part[pt][v] = sp;
+        }
+        __syncthreads();
+        if (tid < 32) {
+            float sp = 0.f;
+            for (int i = 0; i < 8; ++i) sp += part[i][tid];
+            bord[tid >> 3][tid & 7] = sp;
+        }
         __syncthreads();
     }
     if (tid < 72) {
