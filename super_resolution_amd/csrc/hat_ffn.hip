@@ -393,25 +393,6 @@ __global__ __launch_bounds__(WAVES * 64, MINW) void ffn_kernel(const HatFfnDesc 
         stamp(4);
         // ================================ phase C: gate + fc2 ===================================
         if (chunk + 1 < d.chunks) load_a1(chunk + 1);  // next chunk's fc1 weights: in flight during gate + fc2
-#ifdef HAT_FFN_DEBUG_DUMP
-        {   // debug build only: dump chunk 0's U (64 channels of the pixel itself) and the depthwise accumulators
-            float* dbg = d.t_out + (size_t)b * H * W * C;
-            for (int pt = 0; pt < 2; ++pt) {
-                const int y = y0 + 2 * wave + pt, x = x0 + c16;
-                if (y < H && x < W) {
-                    const size_t pix = (size_t)y * W + x;
-                    const int hp = (2 * wave + pt + 1) * HALO_W + c16 + 1;
-                    for (int cc = 0; cc < 16; ++cc) {
-                        const int ch = 16 * g + cc;
-                        dbg[pix * C + ch] = to_f(Us[(size_t)hp * 2 * CH + swz_slot<NSU>(hp, ch / VECN) * VECN + (ch % VECN)]);
-                    }
-                    for (int gi = 0; gi < 4; ++gi)
-                        for (int r = 0; r < 4; ++r) dbg[pix * C + 64 + gi * 16 + 4 * g + r] = dacc[gi][pt][r];
-                }
-            }
-            return;
-        }
-#endif
 #pragma unroll
         for (int pt = 0; pt < 2; ++pt) {
             // gate: G = a * SiLU(g); element (g, j<4) <- a-group 0 channel 4g+j, (g, j>=4) <- a-group 1 channel 4g+j-4
