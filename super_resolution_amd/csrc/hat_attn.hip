@@ -180,68 +180,116 @@ __device__ __forceinline__ float max3_raw(float a, float b, float c) {
     return r;
 }
 
+// D = 24 (C = 144) or 30 (C = 180, six heads): D = 30 pads K / Q to 32 channels (K rows of 4 XOR-swizzled slots), stages
+// and stores with 4-byte accesses (a head's 60-byte slice is only 4-byte aligned) and keeps the ones column at V[30].
+template <int D>
 __global__ __launch_bounds__(256, 2) void ocab_attn_fast_kernel(const bf16_t* __restrict__ q, const bf16_t* __restrict__ kv,
                                                                 const float* __restrict__ bias_rot, bf16_t* __restrict__ out,
                                                                 int H, int W, int C, int heads, int ldq, int ldkv, int ldo) {
     using M = MT<bf16_t>;
     using frag_t = M::frag_t;
-    constexpr int WS = 16, WSE = 24, D = 24, NK = 576, MR = 39, NKT = 36, KCH = 12, PAD = 4;
+    constexpr int WS = 16, WSE = 24, NK = 576, MR = 39, NKT = 36, KCH = 12, PAD = 4;
+    constexpr int KR = D == 24 ? 24 : 32;   // K row length in LDS (elements)
+    constexpr int ONE = D == 24 ? 24 : 30;  // V column that holds 1.0 (the softmax denominator row of O^T)
     constexpr float LOG2E = 1.4426950408889634f;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     bf16_t* Ks = reinterpret_cast<bf16_t*>(smem);                 // [576][24]
-    bf16_t* Vs = Ks + NK * D;                                     // [576][32]: 24 channels, 1.0, zeros
+    bf16_t* Vs = Ks + NK * KR;                                    // [576][32]: D channels, 1.0, zeros
     float* tab = reinterpret_cast<float*>(Vs + NK * 32);          // [39*39]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = lane >> 4, c16 = lane & 15;
     const int wx = blockIdx.x, wy = blockIdx.y;
     const int b = blockIdx.z / heads, h = blockIdx.z - b * heads;
     const size_t img = (size_t)b * H * W;
 
-    // Every global load of the staging phase is issued before the first LDS store (branch-free: out-of-image keys
-    // load a clamped pixel and are zeroed by a select), so the phase costs one memory latency, not nine.
     frag_t qfr[4];   // this wave's four query tiles: query tile qt = window row qt, lane c16 = window column
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const size_t qpix = img + (size_t)(wy * WS + wave + 4 * i) * W + (wx * WS + c16);
-        qfr[i] = M::load(q + qpix * ldq + h * D + 8 * (g < 3 ? g : 2));
-        if (g == 3) qfr[i] = M::zero();
-    }
-    constexpr int NTAB = (MR * MR + 255) / 256, NIT = NK * 4 / 256;
+    constexpr int NTAB = (MR * MR + 255) / 256;
     float tv[NTAB];
 #pragma unroll
     for (int it = 0; it < NTAB; ++it) {
         const int i = tid + it * 256;
         tv[it] = bias_rot[(size_t)h * MR * MR + (i < MR * MR ? i : MR * MR - 1)];
     }
-    u32x4 kq[NIT], vq[NIT];
+    if constexpr (D == 24) {
+        // Every global load of the staging phase is issued before the first LDS store (branch-free: out-of-image keys
+        // load a clamped pixel and are zeroed by a select), so the phase costs one memory latency, not nine.
 #pragma unroll
-    for (int it = 0; it < NIT; ++it) {
-        const int i = tid + it * 256;
-        const int key = i >> 2, c = i & 3;
-        const int kh = key / WSE, kw = key - kh * WSE;
-        const int y = wy * WS - PAD + kh, x = wx * WS - PAD + kw;
-        const int yc = min(max(y, 0), H - 1), xc = min(max(x, 0), W - 1);
-        const bf16_t* p = kv + (img + (size_t)yc * W + xc) * ldkv + h * D + 8 * (c < 3 ? c : 2);
-        kq[it] = *reinterpret_cast<const u32x4*>(p);
-        vq[it] = *reinterpret_cast<const u32x4*>(p + C);
+        for (int i = 0; i < 4; ++i) {
+            const size_t qpix = img + (size_t)(wy * WS + wave + 4 * i) * W + (wx * WS + c16);
+            qfr[i] = M::load(q + qpix * ldq + h * D + 8 * (g < 3 ? g : 2));
+            if (g == 3) qfr[i] = M::zero();
+        }
+        constexpr int NIT = NK * 4 / 256;
+        u32x4 kq[NIT], vq[NIT];
+#pragma unroll
+        for (int it = 0; it < NIT; ++it) {
+            const int i = tid + it * 256;
+            const int key = i >> 2, c = i & 3;
+            const int kh = key / WSE, kw = key - kh * WSE;
+            const int y = wy * WS - PAD + kh, x = wx * WS - PAD + kw;
+            const int yc = min(max(y, 0), H - 1), xc = min(max(x, 0), W - 1);
+            const bf16_t* p = kv + (img + (size_t)yc * W + xc) * ldkv + h * D + 8 * (c < 3 ? c : 2);
+            kq[it] = *reinterpret_cast<const u32x4*>(p);
+            vq[it] = *reinterpret_cast<const u32x4*>(p + C);
+        }
+#pragma unroll
+        for (int it = 0; it < NIT; ++it) {
+            const int i = tid + it * 256;
+            const int key = i >> 2, c = i & 3;
+            const int kh = key / WSE, kw = key - kh * WSE;
+            const int y = wy * WS - PAD + kh, x = wx * WS - PAD + kw;
+            const bool inb = y >= 0 && y < H && x >= 0 && x < W;
+            const int vsw = (key >> 1) & 2;  // rows 4..7 of every 8 swap their 32-byte halves: transposed reads stay conflict-free
+            const u32x4 zero = {0u, 0u, 0u, 0u};
+            // channel 24 = 1.0 for EVERY key (out-of-image keys still count in the softmax denominator)
+            const u32x4 vval = c == 3 ? u32x4{0x00003F80u, 0u, 0u, 0u} : (inb ? vq[it] : zero);
+            *reinterpret_cast<u32x4*>(Vs + key * 32 + 8 * (c ^ vsw)) = vval;
+            if (c < 3) *reinterpret_cast<u32x4*>(Ks + key * KR + 8 * c) = inb ? kq[it] : zero;
+        }
+    } else {
+        // 4-byte staging: dword dw (two channels) of key `key`; dword 15 is the pad of K and [1.0, 0] of V
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const size_t qpix = img + (size_t)(wy * WS + wave + 4 * i) * W + (wx * WS + c16);
+            const unsigned* qp = reinterpret_cast<const unsigned*>(q + qpix * ldq + h * D) + 4 * g;
+            u32x4 v;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) v[j] = qp[min(4 * g + j, D / 2 - 1) - 4 * g];
+            if (g == 3) v[3] = 0u;   // channels 30, 31
+            qfr[i] = __builtin_bit_cast(frag_t, v);
+        }
+        constexpr int BATCH = 12, NPASS = NK * 16 / 256 / BATCH;
+        unsigned* Kd = reinterpret_cast<unsigned*>(Ks);
+        unsigned* Vd = reinterpret_cast<unsigned*>(Vs);
+        for (int ps = 0; ps < NPASS; ++ps) {
+            unsigned kq[BATCH], vq[BATCH];
+#pragma unroll
+            for (int it = 0; it < BATCH; ++it) {
+                const int i = tid + (ps * BATCH + it) * 256;
+                const int key = i >> 4, dw = i & 15;
+                const int kh = key / WSE, kw = key - kh * WSE;
+                const int y = wy * WS - PAD + kh, x = wx * WS - PAD + kw;
+                const int yc = min(max(y, 0), H - 1), xc = min(max(x, 0), W - 1);
+                const unsigned* p = reinterpret_cast<const unsigned*>(kv + (img + (size_t)yc * W + xc) * ldkv + h * D) + min(dw, D / 2 - 1);
+                kq[it] = p[0];
+                vq[it] = p[C / 2];
+            }
+#pragma unroll
+            for (int it = 0; it < BATCH; ++it) {
+                const int i = tid + (ps * BATCH + it) * 256;
+                const int key = i >> 4, dw = i & 15;
+                const int kh = key / WSE, kw = key - kh * WSE;
+                const int y = wy * WS - PAD + kh, x = wx * WS - PAD + kw;
+                const bool inb = y >= 0 && y < H && x >= 0 && x < W;
+                const int slot = dw >> 2, vsw = (key >> 1) & 2, ksw = (key >> 1) & 3;
+                Kd[key * 16 + 4 * (slot ^ ksw) + (dw & 3)] = (inb && dw < D / 2) ? kq[it] : 0u;
+                Vd[key * 16 + 4 * (slot ^ vsw) + (dw & 3)] = dw == 15 ? 0x00003F80u : (inb ? vq[it] : 0u);
+            }
+        }
     }
 #pragma unroll
     for (int it = 0; it < NTAB; ++it) {
         const int i = tid + it * 256;
         if (i < MR * MR) tab[i] = tv[it];
-    }
-#pragma unroll
-    for (int it = 0; it < NIT; ++it) {
-        const int i = tid + it * 256;
-        const int key = i >> 2, c = i & 3;
-        const int kh = key / WSE, kw = key - kh * WSE;
-        const int y = wy * WS - PAD + kh, x = wx * WS - PAD + kw;
-        const bool inb = y >= 0 && y < H && x >= 0 && x < W;
-        const int vsw = (key >> 1) & 2;  // rows 4..7 of every 8 swap their 32-byte halves: transposed reads stay conflict-free
-        const u32x4 zero = {0u, 0u, 0u, 0u};
-        // channel 24 = 1.0 for EVERY key (out-of-image keys still count in the softmax denominator)
-        const u32x4 vval = c == 3 ? u32x4{0x00003F80u, 0u, 0u, 0u} : (inb ? vq[it] : zero);
-        *reinterpret_cast<u32x4*>(Vs + key * 32 + 8 * (c ^ vsw)) = vval;
-        if (c < 3) *reinterpret_cast<u32x4*>(Ks + key * D + 8 * c) = inb ? kq[it] : zero;
     }
     __syncthreads();
 
@@ -261,7 +309,8 @@ __global__ __launch_bounds__(256, 2) void ocab_attn_fast_kernel(const bf16_t* __
         const int qt = wave + 4 * qi4;
         const size_t qpix = img + (size_t)(wy * WS + qt) * W + (wx * WS + c16);
         const frag_t qf = qfr[qi4];
-        const bf16_t* krow = Ks + c16 * D + (g < 3 ? 8 * g : 16);   // lanes g == 3 meet a zero Q fragment
+        // D = 24: lanes g == 3 meet a zero Q fragment and re-read group 2; D = 30: 4 slots per row, XOR-swizzled by the row
+        const bf16_t* krow = D == 24 ? Ks + c16 * KR + (g < 3 ? 8 * g : 16) : Ks + c16 * KR + 8 * (g ^ ((c16 >> 1) & 3));
         f32x4 o[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
         float mrun = -3.0e38f;
 #pragma unroll 1
@@ -273,7 +322,7 @@ __global__ __launch_bounds__(256, 2) void ocab_attn_fast_kernel(const bf16_t* __
             for (int t = 0; t < KCH; ++t) {
                 const float* tb = tbase + toff[t];
                 const f32x4 bias4 = {tb[0], tb[1], tb[2], tb[3]};
-                const frag_t kf = M::load(krow + (kt0 + t) * 16 * D);
+                const frag_t kf = M::load(krow + (kt0 + t) * 16 * KR);
                 s[t] = M::mma(kf, qf, bias4);
             }
             float mx = -3.0e38f;
@@ -309,12 +358,21 @@ __global__ __launch_bounds__(256, 2) void ocab_attn_fast_kernel(const bf16_t* __
                 }
             }
         }
-        // row 24 of O^T is the softmax denominator: lane (c16, g = 2), register o[1][0]
-        const float l = __shfl(o[1][0], 32 + c16);
+        // row ONE of O^T is the softmax denominator: register (ONE - 16) % 4 of lane group (ONE - 16) / 4, second tile
+        const float l = __shfl(o[1][(ONE - 16) & 3], 16 * ((ONE - 16) >> 2) + c16);
         const float inv = 1.0f / l;
         bf16_t* op = out + qpix * ldo + h * D + 4 * g;
-        Vec4<bf16_t>::store(op, o[0] * inv);
-        if (g < 2) Vec4<bf16_t>::store(op + 16, o[1] * inv);
+        if constexpr (D == 24) {
+            Vec4<bf16_t>::store(op, o[0] * inv);
+            if (g < 2) Vec4<bf16_t>::store(op + 16, o[1] * inv);
+        } else {  // 4-byte stores: the head slice is only 4-byte aligned; channels 28, 29 are the last two
+            typedef bf16_t bf2 __attribute__((ext_vector_type(2)));
+            const f32x4 a0 = o[0] * inv, a1 = o[1] * inv;
+            *reinterpret_cast<bf2*>(op) = bf2{(bf16_t)a0[0], (bf16_t)a0[1]};
+            *reinterpret_cast<bf2*>(op + 2) = bf2{(bf16_t)a0[2], (bf16_t)a0[3]};
+            *reinterpret_cast<bf2*>(op + 16) = bf2{(bf16_t)a1[0], (bf16_t)a1[1]};
+            if (g < 3) *reinterpret_cast<bf2*>(op + 18) = bf2{(bf16_t)a1[2], (bf16_t)a1[3]};
+        }
     }
 }
 
@@ -348,9 +406,11 @@ extern "C" int hat_ocab_attention(const void* q, const void* kv, const float* bi
     const int d = C / heads;
     if (d > 32 || d % 2 || ldq < C || ldkv < 2 * C || ldo < C) return HAT_EINVAL;
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
-    if (dtype == HAT_BF16 && d == 24 && ws == 16 && wse == 24 && ldq % 8 == 0 && ldkv % 8 == 0 && ldo % 4 == 0 && C % 8 == 0) {
-        const size_t lds = (size_t)576 * 24 * 2 + (size_t)576 * 32 * 2 + (size_t)39 * 39 * 4;
-        auto kern = ocab_attn_fast_kernel;
+    const bool fast24 = d == 24 && ldq % 8 == 0 && ldkv % 8 == 0 && ldo % 4 == 0 && C % 8 == 0;
+    const bool fast30 = d == 30 && ldq % 2 == 0 && ldkv % 2 == 0 && ldo % 2 == 0 && C % 2 == 0;
+    if (dtype == HAT_BF16 && ws == 16 && wse == 24 && (fast24 || fast30)) {
+        const size_t lds = (size_t)576 * (fast24 ? 24 : 32) * 2 + (size_t)576 * 32 * 2 + (size_t)39 * 39 * 4;
+        auto kern = fast24 ? ocab_attn_fast_kernel<24> : ocab_attn_fast_kernel<30>;
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return (int)e;
         HAT_LAUNCH(kern, dim3(W / ws, H / ws, B * heads), dim3(256), lds, s, reinterpret_cast<const bf16_t*>(q),
