@@ -35,11 +35,11 @@ constexpr int CH = 32;        // hidden channels per chunk (a-part); the chunk a
 constexpr int HALO_W = 18;    // 16 + 2
 constexpr int NPAIR = 5;      // 9 taps, two per k-step
 
-// swizzled 16-byte slot inside a [rows][NS slots] LDS array, NS a power of two <= 16
-template <int NS> __device__ __forceinline__ int swz_slot(int row, int slot) {
-    constexpr int R = 16 / NS;  // rows per 256-byte bank row
-    return slot ^ ((row / R) & (NS - 1));
-}
+// Swizzled 16-byte slot inside the [rows][NS slots] Us array, NS a power of two <= 16: slot ^ (row & (NS-1)).
+// For the 8-slot (128-byte, bf16) rows this is conflict-free for the depthwise operand reads — ds_read_b128's lane
+// groups mix rows 0-3 / 12-15 of one k-half with rows 4-11 of the other, for every tap alignment — and 2-way on the
+// 8-byte fc1 stores (enumerated with the lane groups of MI355X_MICROARCH.md; the earlier (row/2)&7 read 1.75x slower).
+template <int NS> __device__ __forceinline__ int swz_slot(int row, int slot) { return slot ^ (row & (NS - 1)); }
 
 // K of fc1 padded to a multiple of 32 with room for the bias column at k = C
 __host__ __device__ inline int ffn_kp(int C) { return (C + 1 + 31) & ~31; }
