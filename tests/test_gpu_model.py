@@ -133,3 +133,32 @@ def test_deterministic():
     b = net(x)
     torch.cuda.synchronize()
     assert torch.equal(a, b)  # the reference is bit-reproducible run to run
+
+
+def test_headline_size_720p_properties():
+    """BASELINE headline workload (HAT-S x4, 3x720x1280) — too large for the CPU oracle, so size-independent properties:
+    finite output of the right shape, bit-reproducible, the bf16 path agrees with this build's own fp32 path as well as
+    the reference's bf16 agrees with its fp32 (>= 40 dB), and the top-left region equals the same region of a run on the
+    top 256 rows only up to what the two global poolings (ECA, ESC) and the frame border can move (a gross mismatch
+    would expose an indexing fault that only shows at large sizes)."""
+    dev = _dev()
+    x = synth.synth_input(X_SEED, (1, 3, 720, 1280)).to(dev)
+    net16 = build_net("HAT-S_x4", "bf16", dev)
+    y = net16(x).clone()
+    y2 = net16(x)
+    torch.cuda.synchronize()
+    assert y.shape == (1, 3, 2880, 5120) and torch.isfinite(y).all()
+    assert torch.equal(y, y2)
+    del y2
+    net32 = build_net("HAT-S_x4", "f32", dev)
+    y32 = net32(x)
+    torch.cuda.synchronize()
+    assert torch.isfinite(y32).all()
+    mse = float(((y.double() - y32.double()) ** 2).mean())
+    psnr = 10 * np.log10(1.0 / mse)
+    assert psnr >= 40.0, f"bf16 vs fp32 path at 720p: {psnr:.2f} dB"
+    # the same weights on the top 256 rows: far from the cut (rows < 128 of the LR frame) only global statistics differ
+    yc = net32(x[:, :, :256].contiguous())
+    torch.cuda.synchronize()
+    d = (yc[:, :, :512] - y32[:, :, :512]).abs()
+    assert float(d.mean()) < 0.05 * float(y32[:, :, :512].abs().mean()) + 1e-3
