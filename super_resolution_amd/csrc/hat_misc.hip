@@ -185,16 +185,18 @@ __global__ __launch_bounds__(256) void eca_reduce_kernel(const float* __restrict
     const int c = threadIdx.x % lw, sb = threadIdx.x / lw, part = blockIdx.x, b = blockIdx.y;
     const int per = (tiles + 31) / 32;
     const int t0 = part * per, t1 = min(tiles, t0 + per);
-    float s0 = 0.f, s1 = 0.f;
-    if (c < ldc) {
-        int t = t0 + sb;
-        for (; t + nsub < t1; t += 2 * nsub) {
-            s0 += colsum[((size_t)b * tiles + t) * ldc + c];
-            s1 += colsum[((size_t)b * tiles + t + nsub) * ldc + c];
+    float a[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};   // 8 loads in flight per thread
+    if (c < ldc && t1 > t0) {
+        for (int t = t0 + sb; t < t1; t += 8 * nsub) {
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int tt = t + u * nsub;
+                const float v = colsum[((size_t)b * tiles + min(tt, t1 - 1)) * ldc + c];
+                a[u] += tt < t1 ? v : 0.f;
+            }
         }
-        if (t < t1) s0 += colsum[((size_t)b * tiles + t) * ldc + c];
     }
-    sub[threadIdx.x] = s0 + s1;
+    sub[threadIdx.x] = ((a[0] + a[1]) + (a[2] + a[3])) + ((a[4] + a[5]) + (a[6] + a[7]));
     __syncthreads();
     if (sb == 0 && c < ldc) {
         float s = 0.f;
@@ -227,7 +229,8 @@ __global__ __launch_bounds__(256) void eca_scale_kernel(const float* __restrict_
 // ---------------------------------------------------------------------------------------------
 // hat_cab_fold (see include/hat_mi355x.h): one 256-thread workgroup per sample.
 // ---------------------------------------------------------------------------------------------
-template <typename T>
+// DIRECT: few tiles — the workgroup sums the per-tile column sums itself (one launch instead of two)
+template <typename T, bool DIRECT>
 __global__ __launch_bounds__(256) void cab_fold_kernel(const HatCabFoldDesc d) {
     __shared__ float red[256 * 33];  // [thread][4 lines x 8 channels], rows padded to 33 floats
     __shared__ float part[8][32];
@@ -277,11 +280,29 @@ __global__ __launch_bounds__(256) void cab_fold_kernel(const HatCabFoldDesc d) {
         }
         __syncthreads();
     }
+    if constexpr (DIRECT) {  // totals of the 8 channels: 32 interleaved sub-sums per channel, then a fixed-order sum
+        const int c = tid & 7, sb = tid >> 3;
+        float a[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};   // 8 loads in flight per thread
+        for (int t = sb; t < d.tiles; t += 256) {
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int tt = t + 32 * u;
+                const float v = d.c1_colsum[((size_t)b * d.tiles + min(tt, d.tiles - 1)) * d.ldcs + c];
+                a[u] += tt < d.tiles ? v : 0.f;
+            }
+        }
+        part[c][sb] = ((a[0] + a[1]) + (a[2] + a[3])) + ((a[4] + a[5]) + (a[6] + a[7]));
+        __syncthreads();
+    }
     if (tid < 72) {
         const int tap = tid >> 3, c = tid & 7;
         const int dy = tap / 3 - 1, dx = tap % 3 - 1;
         float tot = 0.f;
-        for (int p = 0; p < 32; ++p) tot += d.tmp[((size_t)b * 32 + p) * d.ldcs + c];
+        if constexpr (DIRECT) {
+            for (int p = 0; p < 32; ++p) tot += part[c][p];
+        } else {
+            for (int p = 0; p < 32; ++p) tot += d.tmp[((size_t)b * 32 + p) * d.ldcs + c];
+        }
         // input pixel q = p + (dy,dx) must lie inside: dy=+1 never reads row 0, dy=-1 never reads row H-1 (same for columns)
         float v = tot;
         const int rl = dy == 1 ? 0 : dy == -1 ? 1 : -1, cl = dx == 1 ? 2 : dx == -1 ? 3 : -1;
@@ -295,10 +316,19 @@ __global__ __launch_bounds__(256) void cab_fold_kernel(const HatCabFoldDesc d) {
     }
     __syncthreads();
     float m = 0.f;
-    if (tid < C) {
-        for (int ci = 0; ci < mid; ++ci)
-            for (int tap = 0; tap < 9; ++tap) m += d.w2[((size_t)tid * mid + ci) * 9 + tap] * S[tap][ci];
-        m = m / ((float)H * (float)W) + d.b2[tid];
+    {   // (every global load of this kernel is unconditional and batched: it is one workgroup, so each dependent load
+        // costs a full L2 round trip)
+        const int co = tid < C ? tid : C - 1;
+        float wv[72];
+#pragma unroll
+        for (int q = 0; q < 72; ++q) wv[q] = d.w2[(size_t)co * mid * 9 + min(q, mid * 9 - 1)];
+        const float bb = d.b2[co];
+#pragma unroll
+        for (int q = 0; q < 72; ++q) {
+            const int ci = q / 9, tap = q - ci * 9;
+            if (q < mid * 9) m += wv[q] * S[tap][ci < 8 ? ci : 7];
+        }
+        m = tid < C ? m / ((float)H * (float)W) + bb : 0.f;
     }
     mean[tid] = m;
     __syncthreads();
@@ -317,12 +347,26 @@ __global__ __launch_bounds__(256) void cab_fold_kernel(const HatCabFoldDesc d) {
     const int nt = (C + 15) / 16;
     for (int n = tid; n < nt * 16; n += 256) d.bias_out[(size_t)b * nt * 16 + n] = n < C ? d.bias_in[n] + scl[n] * d.b2[n] : 0.f;
     T* wf = reinterpret_cast<T*>(d.wf) + (size_t)b * nt * 3 * 512;
-    for (int i = tid; i < nt * 3 * 512; i += 256) {
-        const int j = i & 7, lane = (i >> 3) & 63, ks = (i >> 9) % 3, t = i / (3 * 512);
-        const int co = t * 16 + (lane & 15), k = 32 * ks + 8 * (lane >> 4) + j;
-        const int tap = k >> 3, ci = k & 7;
-        const float v = (co < C && tap < 9 && ci < mid) ? scl[co] * d.w2[((size_t)co * mid + ci) * 9 + tap] : 0.f;
-        wf[i] = to_T<T>(v);
+    constexpr int FU = 9;  // elements per thread per batch
+    for (int i0 = tid; i0 < nt * 3 * 512; i0 += 256 * FU) {
+        float wv[FU];
+        bool ok[FU];
+        int cov[FU];
+#pragma unroll
+        for (int u = 0; u < FU; ++u) {
+            const int i = min(i0 + u * 256, nt * 3 * 512 - 1);
+            const int j = i & 7, lane = (i >> 3) & 63, ks = (i >> 9) % 3, t = i / (3 * 512);
+            const int co = t * 16 + (lane & 15), k = 32 * ks + 8 * (lane >> 4) + j;
+            const int tap = k >> 3, ci = k & 7;
+            ok[u] = co < C && tap < 9 && ci < mid;
+            cov[u] = min(co, C - 1);
+            wv[u] = d.w2[((size_t)cov[u] * mid + min(ci, mid - 1)) * 9 + min(tap, 8)];
+        }
+#pragma unroll
+        for (int u = 0; u < FU; ++u) {
+            const int i = i0 + u * 256;
+            if (i < nt * 3 * 512) wf[i] = to_T<T>(ok[u] ? scl[cov[u]] * wv[u] : 0.f);
+        }
     }
 }
 
@@ -417,12 +461,17 @@ extern "C" int hat_cab_fold(const HatCabFoldDesc* dp, void* stream) {
         d.ldcs > 256 || d.k < 1 || (d.k & 1) == 0 || d.ld_scale < d.C)
         return HAT_EINVAL;
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    if (d.dtype != HAT_BF16 && d.dtype != HAT_F32) return HAT_EINVAL;
+    if (d.tiles <= 2048) {
+        if (d.dtype == HAT_BF16) HAT_LAUNCH((cab_fold_kernel<bf16_t, true>), dim3(d.B), dim3(256), 0, s, d);
+        else HAT_LAUNCH((cab_fold_kernel<float, true>), dim3(d.B), dim3(256), 0, s, d);
+        return hat_check_launch();
+    }
     HAT_LAUNCH(eca_reduce_kernel, dim3(32, d.B), dim3(256), 0, s, d.c1_colsum, d.tiles, d.ldcs, d.tmp);
     int rc = hat_check_launch();
     if (rc) return rc;
-    if (d.dtype == HAT_BF16) HAT_LAUNCH(cab_fold_kernel<bf16_t>, dim3(d.B), dim3(256), 0, s, d);
-    else if (d.dtype == HAT_F32) HAT_LAUNCH(cab_fold_kernel<float>, dim3(d.B), dim3(256), 0, s, d);
-    else return HAT_EINVAL;
+    if (d.dtype == HAT_BF16) HAT_LAUNCH((cab_fold_kernel<bf16_t, false>), dim3(d.B), dim3(256), 0, s, d);
+    else HAT_LAUNCH((cab_fold_kernel<float, false>), dim3(d.B), dim3(256), 0, s, d);
     return hat_check_launch();
 }
 
