@@ -245,15 +245,25 @@ class HATEngine:
         return w
 
     # ------------------------------------------------------------------------------------------
-    def _esc_lk(self, esc: _ESC, w, n, B, H, W, nblk):
-        """ESC large-kernel + dynamic depthwise conv on the first pdim channels of `n` -> w['y16']."""
-        dt, C = self.dtype, self.C
-        N = H * W
-        ops.esc_weights(w["gap"], nblk, N, esc.w1, esc.b1, esc.w2, esc.b2, esc.plk, w["weff"], B=B,
-                        pdim=esc.pdim, ksize=esc.ksize, kpad=esc.kpad, dtype=dt)
+    def _esc_w(self, esc: _ESC, w, B, H, W, nblk):
+        """The per-sample 13x13 weights of the ESC conv (static filter + dynamic depthwise kernel) -> w['weff']."""
+        ops.esc_weights(w["gap"], nblk, H * W, esc.w1, esc.b1, esc.w2, esc.b2, esc.plk, w["weff"], B=B,
+                        pdim=esc.pdim, ksize=esc.ksize, kpad=esc.kpad, dtype=self.dtype)
+
+    def _esc_conv(self, esc: _ESC, w, n, B, H, W):
         pw = ops.PackedConv(w["weff"], esc.zero_bias, esc.ksize, esc.pdim, esc.kpad, 1, 1, esc.pdim,
                             w_bstride=16 * esc.kpad)
-        ops.conv(pw, n, w["y16"], B=B, H=H, W=W, dtype=dt, ldx=_r8(C), ldo=16, n_store=_r4(esc.pdim))
+        ops.conv(pw, n, w["y16"], B=B, H=H, W=W, dtype=self.dtype, ldx=_r8(self.C), ldo=16, n_store=_r4(esc.pdim))
+
+    def _esc_lk(self, esc: _ESC, w, n, B, H, W, nblk):
+        """ESC large-kernel + dynamic depthwise conv on the first pdim channels of `n` -> w['y16']."""
+        self._esc_w(esc, w, B, H, W, nblk)
+        self._esc_conv(esc, w, n, B, H, W)
+
+    def _side_stream(self):
+        if getattr(self, "_s1", None) is None:
+            self._s1 = torch.cuda.Stream(device=self.dev)
+        return self._s1
 
     def forward(self, x: torch.Tensor) -> torch.Tensor:
         if not x.is_cuda:
@@ -299,13 +309,24 @@ class HATEngine:
                 mid = hb["cab0"].nout
                 if "fold" in hb:
                     # c2 = conv3x3(c1) never exists: its ECA pooling follows from the sums of c1 (hat_cab_fold) and the
-                    # scaled expand conv is three more k-steps of the aggregation GEMM (hat_aggr_cab)
+                    # scaled expand conv is three more k-steps of the aggregation GEMM (hat_aggr_cab).
+                    # The two tiny per-sample kernels (one workgroup each, latency-bound) run on a side stream next to the
+                    # convs they do not depend on: esc_weights beside the CAB squeeze conv, cab_fold beside the 13x13 conv.
                     fo = hb["fold"]
+                    s0, s1 = torch.cuda.current_stream(), self._side_stream()
+                    s1.wait_stream(s0)                              # GAP partials (previous FFN / LayerNorm) are ready
+                    with torch.cuda.stream(s1):
+                        self._esc_w(esc, w, B, H, W, nblk)
+                        ev_w = s1.record_event()
                     ops.conv(hb["cab0"], w["n"], w["c1"], **geo, ldx=ldc, ldo=8, act=ACT_GELU, n_store=8, colsum=w["colsum1"])
-                    ops.cab_fold(w["c1"], w["colsum1"], w["tiles1"], hb["cab0"].npad, fo["w2"], fo["b2"], hb["eca_w"],
-                                 hb["eca_w"].numel(), fo["ba"], float(cfg["conv_scale"]), w["scale"], w["wf"], w["bias_b"],
-                                 w["eca_tmp"], B=B, H=H, W=W, C_=C, mid=mid, dtype=dt)
-                    self._esc_lk(esc, w, w["n"], B, H, W, nblk)
+                    s1.wait_stream(s0)                              # c1 and its column sums are ready
+                    with torch.cuda.stream(s1):
+                        ops.cab_fold(w["c1"], w["colsum1"], w["tiles1"], hb["cab0"].npad, fo["w2"], fo["b2"], hb["eca_w"],
+                                     hb["eca_w"].numel(), fo["ba"], float(cfg["conv_scale"]), w["scale"], w["wf"], w["bias_b"],
+                                     w["eca_tmp"], B=B, H=H, W=W, C_=C, mid=mid, dtype=dt)
+                    s0.wait_event(ev_w)
+                    self._esc_conv(esc, w, w["n"], B, H, W)
+                    s0.wait_stream(s1)                              # folded weights, bias and scale are ready
                     ops.aggr_cab(esc.aggr, w["n"], tB, w["c1"], w["wf"], w["bias_b"], **geo, ldx=ldc, ldo=C, x0=w["y16"],
                                  c_split=esc.pdim, ldx0=16, r1=t, ldr1=C)
                     pre_ln = False
