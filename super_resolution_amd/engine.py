@@ -314,19 +314,16 @@ class HATEngine:
                     # convs they do not depend on: esc_weights beside the CAB squeeze conv, cab_fold beside the 13x13 conv.
                     fo = hb["fold"]
                     s0, s1 = torch.cuda.current_stream(), self._side_stream()
-                    s1.wait_stream(s0)                              # GAP partials (previous FFN / LayerNorm) are ready
-                    with torch.cuda.stream(s1):
+                    s1.wait_stream(s0)                              # n and its GAP partials are ready
+                    with torch.cuda.stream(s1):                     # chain 2: ESC weights -> 13x13 conv
                         self._esc_w(esc, w, B, H, W, nblk)
-                        ev_w = s1.record_event()
+                        self._esc_conv(esc, w, w["n"], B, H, W)
+                    # chain 1: CAB squeeze conv -> fold
                     ops.conv(hb["cab0"], w["n"], w["c1"], **geo, ldx=ldc, ldo=8, act=ACT_GELU, n_store=8, colsum=w["colsum1"])
-                    s1.wait_stream(s0)                              # c1 and its column sums are ready
-                    with torch.cuda.stream(s1):
-                        ops.cab_fold(w["c1"], w["colsum1"], w["tiles1"], hb["cab0"].npad, fo["w2"], fo["b2"], hb["eca_w"],
-                                     hb["eca_w"].numel(), fo["ba"], float(cfg["conv_scale"]), w["scale"], w["wf"], w["bias_b"],
-                                     w["eca_tmp"], B=B, H=H, W=W, C_=C, mid=mid, dtype=dt)
-                    s0.wait_event(ev_w)
-                    self._esc_conv(esc, w, w["n"], B, H, W)
-                    s0.wait_stream(s1)                              # folded weights, bias and scale are ready
+                    ops.cab_fold(w["c1"], w["colsum1"], w["tiles1"], hb["cab0"].npad, fo["w2"], fo["b2"], hb["eca_w"],
+                                 hb["eca_w"].numel(), fo["ba"], float(cfg["conv_scale"]), w["scale"], w["wf"], w["bias_b"],
+                                 w["eca_tmp"], B=B, H=H, W=W, C_=C, mid=mid, dtype=dt)
+                    s0.wait_stream(s1)                              # y16 is ready
                     ops.aggr_cab(esc.aggr, w["n"], tB, w["c1"], w["wf"], w["bias_b"], **geo, ldx=ldc, ldo=C, x0=w["y16"],
                                  c_split=esc.pdim, ldx0=16, r1=t, ldr1=C)
                     pre_ln = False
@@ -373,8 +370,12 @@ class HATEngine:
                 self._esc_lk(esc, w, w["n"], B, H, W, nblk)
                 self._run_lin(esc.aggr, w["n"], w["yesc"], **geo, ldx=ldc, ldo=ldc, x0=w["y16"], c_split=esc.pdim, ldx0=16)
                 kv_src = w["yesc"]
-            self._run_lin(oc["q"], w["n"], w["q"], **geo, ldx=ldc, ldo=ldc)
+            s0, s1 = torch.cuda.current_stream(), self._side_stream()   # q and kv projections are independent
+            s1.wait_stream(s0)
+            with torch.cuda.stream(s1):
+                self._run_lin(oc["q"], w["n"], w["q"], **geo, ldx=ldc, ldo=ldc)
             self._run_lin(oc["kv"], kv_src, w["kv"], **geo, ldx=ldc, ldo=w["kv"].shape[2])
+            s0.wait_stream(s1)
             ops.ocab_attention(w["q"], w["kv"], oc["bias_rot"], w["ao"], B=B, H=H, W=W, C_=C, heads=L["heads"], ws=ws,
                                wse=self.wse, ldq=ldc, ldkv=w["kv"].shape[2], ldo=ldc, dtype=dt)
             tout = tB if t is tA else t  # never write the RHAG input buffer
