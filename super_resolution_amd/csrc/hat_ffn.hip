@@ -48,9 +48,9 @@ template <typename T, bool MSWZ> __host__ __device__ inline int ffn_ldm(int C) {
     return MSWZ ? ffn_kp(C) : lds_row_elems(ffn_kp(C), sizeof(T));
 }
 
-template <typename T, int WAVES, bool MSWZ>
+template <typename T, int WAVES, bool MSWZ, int RPW = 2>
 __host__ __device__ inline size_t ffn_lds_bytes(int C) {
-    const int nph = (2 * WAVES + 2) * HALO_W;
+    const int nph = (RPW * WAVES + 2) * HALO_W;
     const size_t ms = ((size_t)nph * ffn_ldm<T, MSWZ>(C) * sizeof(T) + 255) & ~(size_t)255;  // Us starts 256-byte aligned
     const size_t us = (size_t)(nph + 1) * 2 * CH * sizeof(T);  // + the constant-one row (depthwise bias)
     return ms + us;
@@ -63,12 +63,14 @@ __device__ __forceinline__ float silu_exact(float x) { return x / (1.0f + expf(-
 //   1 skip LN stage, 2 skip fc1 MFMA loop, 4 skip the dw MFMAs, 8 skip gate math, 16 skip fc2 MFMAs,
 //   32 skip all weight-fragment loads, 64 per-phase s_memtime totals of every wave -> gap_out[wg][wave][8]
 // MINW = waves per SIMD the register allocation must allow (2 when two workgroups' LDS fit one CU)
-template <typename T, int WAVES, int NT, int KS, bool MSWZ, int MINW, int DBG = 0>
+// RPW = tile rows per wave in the depthwise / gate / fc2 phases (2, or 1 when eight waves share an 8-row tile because the
+// LDS image is too large for two workgroups per CU: C = 180)
+template <typename T, int WAVES, int NT, int KS, bool MSWZ, int MINW, int DBG = 0, int RPW = 2>
 __global__ __launch_bounds__(WAVES * 64, MINW) void ffn_kernel(const HatFfnDesc d) {
     using M = MT<T>;
     using frag_t = typename M::frag_t;
     constexpr int NTHR = WAVES * 64;
-    constexpr int TROWS = 2 * WAVES;
+    constexpr int TROWS = RPW * WAVES;
     constexpr int NPH = (TROWS + 2) * HALO_W;     // haloed pixels
     constexpr int NPT = (NPH + 15) / 16;          // fc1 pixel tiles over the flattened halo tile
     constexpr int VECN = M::VEC;                  // elements per 16 bytes
@@ -206,10 +208,10 @@ __global__ __launch_bounds__(WAVES * 64, MINW) void ffn_kernel(const HatFfnDesc 
     // persistent fc2 accumulators: this wave's two tile rows x all NT channel tiles, initialised with the residual
     // t_in + b2 (clamped, unconditional loads that complete during chunk 0; out-of-image pixels and pad channels hold
     // values that are never stored)
-    f32x4 acc2[NT][2];
+    f32x4 acc2[NT][RPW];
 #pragma unroll
-    for (int pt = 0; pt < 2; ++pt) {
-        const size_t pixc = (size_t)min(y0 + 2 * wave + pt, H - 1) * W + min(x0 + c16, W - 1);
+    for (int pt = 0; pt < RPW; ++pt) {
+        const size_t pixc = (size_t)min(y0 + RPW * wave + pt, H - 1) * W + min(x0 + c16, W - 1);
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) {
             const int n = nt * 16 + 4 * g;
@@ -269,7 +271,7 @@ __global__ __launch_bounds__(WAVES * 64, MINW) void ffn_kernel(const HatFfnDesc 
     // bytes and Us is ROWB-aligned, so group gi's fragment is at uoff ^ (gi * ROWB / 4): one v_xor per read,
     // and the ten addresses are chunk-invariant.
     constexpr unsigned ROWB = 2 * CH * sizeof(T);
-    unsigned uoff[NPAIR][2];
+    unsigned uoff[NPAIR][RPW];
     {
         const unsigned usb = (unsigned)(uintptr_t)(__attribute__((address_space(3))) char*)(char*)Us;
 #pragma unroll
@@ -277,9 +279,9 @@ __global__ __launch_bounds__(WAVES * 64, MINW) void ffn_kernel(const HatFfnDesc 
             const int tapr = 2 * pr + (g >> 1);
             const int tap = tapr < 9 ? tapr : 8;
             const int dy = (tap * 11) >> 5, dx = tap - 3 * dy;
-            const int hp0 = (2 * wave + dy) * HALO_W + c16 + dx;   // row 0 of this wave; row 1 is one halo row below
+            const int hp0 = (RPW * wave + dy) * HALO_W + c16 + dx;   // row 0 of this wave; row 1 is one halo row below
 #pragma unroll
-            for (int pt = 0; pt < 2; ++pt) {
+            for (int pt = 0; pt < RPW; ++pt) {
                 const int hp = tapr < 9 ? hp0 + pt * HALO_W : NPH;
                 uoff[pr][pt] = usb + (unsigned)hp * ROWB + (unsigned)swz_slot<NSU>(hp, (BF ? 1 : 2) * (g & 1)) * 16u;
             }
@@ -346,9 +348,11 @@ __global__ __launch_bounds__(WAVES * 64, MINW) void ffn_kernel(const HatFfnDesc 
         stamp(3);
 
         // ============ phase B: depthwise 3x3 as MFMA with diagonal weights (this wave's two rows) ============
-        f32x4 dacc[4][2];
+        f32x4 dacc[4][RPW];
 #pragma unroll
-        for (int gi = 0; gi < 4; ++gi) { dacc[gi][0] = f32x4{0.f, 0.f, 0.f, 0.f}; dacc[gi][1] = dacc[gi][0]; }
+        for (int gi = 0; gi < 4; ++gi)
+#pragma unroll
+            for (int pt = 0; pt < RPW; ++pt) dacc[gi][pt] = f32x4{0.f, 0.f, 0.f, 0.f};
         frag_t a2[NT];  // fc2 weights: issued half-way through the depthwise steps, consumed after the gate math
         auto load_a2 = [&]() {
 #pragma unroll
@@ -361,10 +365,10 @@ __global__ __launch_bounds__(WAVES * 64, MINW) void ffn_kernel(const HatFfnDesc 
             // (Pinning the reads further ahead with sched_barrier measured no faster — the other wave on the SIMD
             // already covers the LDS latency — and cost 84 bytes/lane of scratch.)
             constexpr int NSTEP = NPAIR * 4, AHEAD = 2, DEPTH = AHEAD + 1;
-            frag_t ub[DEPTH][2];
+            frag_t ub[DEPTH][RPW];
             auto issue = [&](int st) {
-                ub[st % DEPTH][0] = ldu(st >> 2, 0, st & 3);
-                ub[st % DEPTH][1] = ldu(st >> 2, 1, st & 3);
+#pragma unroll
+                for (int pt = 0; pt < RPW; ++pt) ub[st % DEPTH][pt] = ldu(st >> 2, pt, st & 3);
             };
 #pragma unroll
             for (int st = 0; st < AHEAD; ++st) issue(st);
@@ -386,15 +390,15 @@ __global__ __launch_bounds__(WAVES * 64, MINW) void ffn_kernel(const HatFfnDesc 
 #pragma unroll
                     for (int jj = 0; jj < 8; ++jj) af[jj] = (jj == jstar) ? wdw[gi * NPAIR + pr] : 0.f;
                 }
-                dacc[gi][0] = M::mma(af, ub[st % DEPTH][0], dacc[gi][0]);
-                dacc[gi][1] = M::mma(af, ub[st % DEPTH][1], dacc[gi][1]);
+#pragma unroll
+                for (int pt = 0; pt < RPW; ++pt) dacc[gi][pt] = M::mma(af, ub[st % DEPTH][pt], dacc[gi][pt]);
             }
         }
         stamp(4);
         // ================================ phase C: gate + fc2 ===================================
         if (chunk + 1 < d.chunks) load_a1(chunk + 1);  // next chunk's fc1 weights: in flight during gate + fc2
 #pragma unroll
-        for (int pt = 0; pt < 2; ++pt) {
+        for (int pt = 0; pt < RPW; ++pt) {
             // gate: G = a * SiLU(g); element (g, j<4) <- a-group 0 channel 4g+j, (g, j>=4) <- a-group 1 channel 4g+j-4
             frag_t gf;
 #pragma unroll
@@ -431,8 +435,8 @@ __global__ __launch_bounds__(WAVES * 64, MINW) void ffn_kernel(const HatFfnDesc 
         }
     }
 #pragma unroll
-    for (int pt = 0; pt < 2; ++pt) {
-        const int y = y0 + 2 * wave + pt, x = x0 + c16;
+    for (int pt = 0; pt < RPW; ++pt) {
+        const int y = y0 + RPW * wave + pt, x = x0 + c16;
         const bool valid = y < H && x < W;
         const size_t pix = (size_t)y * W + x;
         float s = 0.f;
@@ -501,26 +505,26 @@ __global__ __launch_bounds__(WAVES * 64, MINW) void ffn_kernel(const HatFfnDesc 
     }
 }
 
-template <typename T, int WAVES, int NT, int KS, bool MSWZ, int MINW>
+template <typename T, int WAVES, int NT, int KS, bool MSWZ, int MINW, int RPW = 2>
 int launch_ffn(const HatFfnDesc& d, hipStream_t s) {
     if (ffn_kp(d.C) != KS * 32 || (d.C + 15) / 16 != NT) return HAT_EUNSUPPORTED;
-    const size_t lds = ffn_lds_bytes<T, WAVES, MSWZ>(d.C);
+    const size_t lds = ffn_lds_bytes<T, WAVES, MSWZ, RPW>(d.C);
     if (lds > HAT_LDS_MAX) return HAT_ELDS;
-    auto kern = ffn_kernel<T, WAVES, NT, KS, MSWZ, MINW>;
+    auto kern = ffn_kernel<T, WAVES, NT, KS, MSWZ, MINW, 0, RPW>;
     if (lds > 65536) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return (int)e;
     }
-    dim3 grid((d.W + 15) / 16, (d.H + 2 * WAVES - 1) / (2 * WAVES), d.B);
+    dim3 grid((d.W + 15) / 16, (d.H + RPW * WAVES - 1) / (RPW * WAVES), d.B);
     HAT_LAUNCH(kern, grid, dim3(WAVES * 64), lds, s, d);
     return hat_check_launch();
 }
 
-// tile rows (= 2 * waves) used for (C, dtype); 0 if the shape is not instantiated
-int ffn_waves(const HatFfnDesc& d) {
+// tile rows used for (C, dtype); 0 if the shape is not instantiated
+int ffn_rows(const HatFfnDesc& d) {
     const bool small = d.C <= 32 && d.C % 32 != 16;  // one zero-padded 32-deep k-step
-    if (d.dtype == HAT_BF16) return (d.C == 144 || d.C == 180 || small) ? 4 : 0;
-    if (d.dtype == HAT_F32) return (d.C == 144 || d.C == 180 || small) ? 2 : 0;
+    if (d.dtype == HAT_BF16) return (d.C == 144 || d.C == 180 || small) ? 8 : 0;
+    if (d.dtype == HAT_F32) return (d.C == 144 || d.C == 180 || small) ? 4 : 0;
     return 0;
 }
 
@@ -528,9 +532,9 @@ int ffn_waves(const HatFfnDesc& d) {
 
 extern "C" int hat_ffn_tiles(const HatFfnDesc* d, int32_t* tiles_out) {
     if (!d || !tiles_out) return HAT_EINVAL;
-    const int wv = ffn_waves(*d);
-    if (!wv) return HAT_EUNSUPPORTED;
-    *tiles_out = ((d->W + 15) / 16) * ((d->H + 2 * wv - 1) / (2 * wv));
+    const int rows = ffn_rows(*d);
+    if (!rows) return HAT_EUNSUPPORTED;
+    *tiles_out = ((d->W + 15) / 16) * ((d->H + rows - 1) / rows);
     return 0;
 }
 
@@ -546,7 +550,7 @@ extern "C" int hat_ffn(const HatFfnDesc* dp, void* stream) {
     const bool small = d.C <= 32 && d.C % 32 != 16;
     if (d.dtype == HAT_BF16) {
         if (d.C == 144) return launch_ffn<bf16_t, 4, 9, 5, true, 2>(d, s);
-        if (d.C == 180) return launch_ffn<bf16_t, 4, 12, 6, false, 1>(d, s);
+        if (d.C == 180) return launch_ffn<bf16_t, 8, 12, 6, false, 2, 1>(d, s);  // 98 KB of LDS: one workgroup of eight waves per CU
         if (small) return launch_ffn<bf16_t, 4, 2, 1, true, 2>(d, s);
     } else if (d.dtype == HAT_F32) {
         if (d.C == 144) return launch_ffn<float, 2, 9, 5, false, 1>(d, s);
