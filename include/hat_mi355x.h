@@ -199,6 +199,24 @@ int hat_ocab_attention(const void* q, const void* kv, const float* bias_rot, voi
                        int32_t ldkv, int32_t ldo, int32_t dtype, void* stream);
 
 /*
+ * (Shifted-)window self-attention, (S)W-MSA — SURVEY §8 row f2.  Replaces, for one attention branch of a Swin / upstream-HAT
+ * block, ESC/basicsr/archs/swinir_arch.py:291-317 (torch.roll by -shift, window_partition, WindowAttention core :147-168
+ * with the relative-position bias :153-156 and the shift mask of calculate_mask :262-280, window_reverse, torch.roll by
+ * +shift); the same buffers this fork's HAT still registers (hat_arch.py:770-781, 805-818).  The two Linear layers
+ * (qkv :146, proj :169) are hat_linear launches on either side.
+ * q: (B,H,W,ldq) T, already multiplied by head_dim^-0.5; kv: (B,H,W,ldkv) T with k at channel 0 and v at channel C (for
+ * a packed qkv map of row stride 3C: q = base, kv = base + C); head h owns channels [h*d, (h+1)*d), d = C/heads even, <= 32.
+ * bias_flip: [heads][(2ws-1)^2] fp32 with bias_flip[h][i] = relative_position_bias_table[(2ws-1)^2 - 1 - i][h]
+ * (the kernel indexes by key - query offsets, the reference's relative_position_index by query - key).
+ * shift: 0 (W-MSA) or a multiple of 4 below ws (SW-MSA; the reference uses ws/2): windows are taken on the cyclically
+ * shifted frame and pairs in different mask bands get -100 added to the logit (not -inf), as in the reference.
+ * out: (B,H,W,ldo) T at the un-shifted pixel positions.  ws in {8, 16}; H, W multiples of ws.
+ */
+int hat_window_attention(const void* q, const void* kv, const float* bias_flip, void* out, int32_t B, int32_t H,
+                         int32_t W, int32_t C, int32_t heads, int32_t ws, int32_t shift, int32_t ldq, int32_t ldkv,
+                         int32_t ldo, int32_t dtype, void* stream);
+
+/*
  * Fused HAB feed-forward half (hat_arch.py:237 with :107-119):
  *     t_out = t_in + fc2( a * SiLU(g) ),  [a | g] = dwconv3x3( fc1( LayerNorm2(t_in) ) )
  * in ONE kernel: the 4C-wide intermediate never leaves the CU (LDS), HBM traffic is one read and one

@@ -175,6 +175,47 @@ def ocab_attention(q: Tensor, k: Tensor, v: Tensor, table: Tensor, rpi: Tensor, 
     return o.reshape(b, h, w, c)
 
 
+def sw_msa_mask(h: int, w: int, ws: int, shift: int) -> Tensor:
+    """Shift mask of SW-MSA: ESC/basicsr/archs/swinir_arch.py:262-280 (same construction as the dead hat_arch.py:805-818).  Region ids are
+    assigned on the SHIFTED frame in 3 x 3 bands ([0, h-ws), [h-ws, h-shift), [h-shift, h)); pairs of window positions in
+    different regions get -100 (not -inf), same region 0.  Returns (nW, ws*ws, ws*ws)."""
+    def band(n):
+        r = torch.zeros(n, dtype=torch.int64)
+        r[n - ws:n - shift] = 1
+        r[n - shift:] = 2
+        return r
+    rid = (3 * band(h)[:, None] + band(w)[None, :]).reshape(h // ws, ws, w // ws, ws).permute(0, 2, 1, 3).reshape(-1, ws * ws)
+    diff = rid[:, None, :] != rid[:, :, None]
+    return torch.where(diff, torch.tensor(-100.0), torch.tensor(0.0))
+
+
+def window_msa(x: Tensor, sd: SD, p: str, ws: int, heads: int, shift: int) -> Tensor:
+    """(S)W-MSA branch of a Swin/HAT block on an already-normalised map x (B,H,W,C): cyclic shift, window partition,
+    WindowAttention, window reverse, reverse shift — ESC/basicsr/archs/swinir_arch.py:291-317 with WindowAttention.forward :140-172
+    (upstream HAT's HAB attention; this fork's HAB dropped it).  Parameters under prefix `p`:
+    qkv.{weight,bias} (3C,C), proj.{weight,bias}, relative_position_bias_table ((2ws-1)^2, heads); the index is rpi_sa."""
+    b, h, w, c = x.shape
+    d = c // heads
+    nh, nw = h // ws, w // ws
+    if shift:
+        x = torch.roll(x, shifts=(-shift, -shift), dims=(1, 2))                                   # :297-298
+    xw = x.reshape(b, nh, ws, nw, ws, c).permute(0, 1, 3, 2, 4, 5).reshape(b * nh * nw, ws * ws, c)  # :303-304
+    qkv = F.linear(xw, sd[p + ".qkv.weight"], sd[p + ".qkv.bias"]).reshape(-1, ws * ws, 3, heads, d).permute(2, 0, 3, 1, 4)
+    q, k, v = qkv[0] * d ** -0.5, qkv[1], qkv[2]                                                   # :147-151
+    attn = q @ k.transpose(-2, -1)
+    bias = sd[p + ".relative_position_bias_table"][rpi_sa(ws).reshape(-1)].reshape(ws * ws, ws * ws, heads)
+    attn = attn + bias.permute(2, 0, 1)[None]                                                      # :153-156
+    if shift:
+        attn = attn.reshape(b, nh * nw, heads, ws * ws, ws * ws) + sw_msa_mask(h, w, ws, shift)[None, :, None]
+        attn = attn.reshape(-1, heads, ws * ws, ws * ws)                                           # :158-161
+    o = (torch.softmax(attn, dim=-1) @ v).transpose(1, 2).reshape(-1, ws * ws, c)                  # :162-168
+    o = F.linear(o, sd[p + ".proj.weight"], sd[p + ".proj.bias"])                                  # :169
+    o = o.reshape(b, nh, nw, ws, ws, c).permute(0, 1, 3, 2, 4, 5).reshape(b, h, w, c)              # :312-313
+    if shift:
+        o = torch.roll(o, shifts=(shift, shift), dims=(1, 2))                                      # :316-317
+    return o
+
+
 def ocab(t: Tensor, hw, sd: SD, p: str, rpi: Tensor, cfg: dict, heads: int) -> Tensor:
     """OCAB.forward, hat_arch.py:326-393."""
     b, _, c = t.shape

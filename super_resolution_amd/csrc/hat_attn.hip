@@ -19,10 +19,16 @@ template <typename T> __device__ __forceinline__ float exp_t(float x);
 template <> __device__ __forceinline__ float exp_t<float>(float x) { return expf(x); }
 template <> __device__ __forceinline__ float exp_t<bf16_t>(float x) { return __expf(x); }
 
-template <typename T, int NKT, int KCH>
+// SELF = true turns the same kernel into (shifted-)window self-attention, (S)W-MSA of swinir_arch.py:140-172, 291-317:
+// the key window is the query window (wse == ws), window coordinates live on the cyclically shifted frame (pixel
+// (Y, X) of the shifted frame is pixel ((Y + shift) % H, (X + shift) % W) of the map, so the two torch.roll calls become
+// addressing), and pairs whose positions fall in different bands of the shift mask (:262-280) get -100 added after the
+// bias, exactly as the reference adds its mask tensor.
+template <typename T, int NKT, int KCH, bool SELF>
 __global__ __launch_bounds__(256) void ocab_attn_kernel(const T* __restrict__ q, const T* __restrict__ kv,
                                                         const float* __restrict__ bias_rot, T* __restrict__ out, int H, int W,
-                                                        int C, int heads, int ws, int wse, int ldq, int ldkv, int ldo) {
+                                                        int C, int heads, int ws, int wse, int ldq, int ldkv, int ldo,
+                                                        int shift) {
     using M = MT<T>;
     constexpr int NK = NKT * 16;
     static_assert(NKT % KCH == 0, "key tiles must split evenly into chunks");
@@ -50,7 +56,11 @@ __global__ __launch_bounds__(256) void ocab_attn_kernel(const T* __restrict__ q,
     for (int i = tid; i < NK * cpk; i += 256) {
         const int key = i / cpk, c = (i - key * cpk) * 2;
         const int kh = key / wse, kw = key - kh * wse;
-        const int y = wy * ws - pad + kh, x = wx * ws - pad + kw;
+        int y = wy * ws - pad + kh, x = wx * ws - pad + kw;
+        if (SELF) {
+            y += shift; if (y >= H) y -= H;
+            x += shift; if (x >= W) x -= W;
+        }
         T k0 = to_T<T>(0.f), k1 = k0, v0 = k0, v1 = k0;
         if (c < d && y >= 0 && y < H && x >= 0 && x < W) {
             const T* p = kv + (img + (size_t)y * W + x) * ldkv + h * d + c;
@@ -67,7 +77,14 @@ __global__ __launch_bounds__(256) void ocab_attn_kernel(const T* __restrict__ q,
         // ---- Q fragment (B operand): this lane's query, channels 8g..8g+7 --------------------
         const int qi = qt * 16 + c16;
         const int qy = qi / ws, qx = qi - qy * ws;
-        const size_t qpix = img + (size_t)(wy * ws + qy) * W + (wx * ws + qx);
+        int qyo = wy * ws + qy, qxo = wx * ws + qx;   // position on the (shifted) frame -> pixel of the map
+        auto band = [&](int v, int n) { return v < n - ws ? 0 : (v < n - shift ? 1 : 2); };
+        const int rid_q = SELF ? 3 * band(qyo, H) + band(qxo, W) : 0;
+        if (SELF) {
+            qyo += shift; if (qyo >= H) qyo -= H;
+            qxo += shift; if (qxo >= W) qxo -= W;
+        }
+        const size_t qpix = img + (size_t)qyo * W + qxo;
         typename M::frag_t qf;
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
@@ -94,9 +111,12 @@ __global__ __launch_bounds__(256) void ocab_attn_kernel(const T* __restrict__ q,
 #pragma unroll
             for (int t = 0; t < KCH; ++t) {
                 const float* tb = tab + (kh - qy + ws - 1) * Mr + (kw - qx + ws - 1);
+                // the lane's 4 keys share a mask band: shift % 4 == 0 and kw % 4 == 0
+                const float madd = (SELF && shift > 0 && 3 * band(wy * ws + kh, H) + band(wx * ws + kw, W) != rid_q) ? -100.0f : 0.0f;
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     s[t][r] += tb[r];
+                    if (SELF) s[t][r] += madd;
                     mx = fmaxf(mx, s[t][r]);
                 }
                 kw += 16;
@@ -376,23 +396,23 @@ __global__ __launch_bounds__(256, 2) void ocab_attn_fast_kernel(const bf16_t* __
     }
 }
 
-template <typename T, int NKT, int KCH>
+template <typename T, int NKT, int KCH, bool SELF = false>
 int launch_attn(const void* q, const void* kv, const float* bias_rot, void* out, int B, int H, int W, int C, int heads,
-                int ws, int wse, int ldq, int ldkv, int ldo, hipStream_t s) {
+                int ws, int wse, int ldq, int ldkv, int ldo, hipStream_t s, int shift = 0) {
     const int es = sizeof(T);
     const int Mr = ws + wse - 1;
     const int d = C / heads, dk8 = (d + 7) & ~7, dv = (d + 1) & ~1;
     const size_t kvb = ((size_t)NKT * 16 * lds_row_elems(dk8, es) + (size_t)dv * lds_row_elems(NKT * 16, es)) * es;
     const size_t lds = (kvb + 15) / 16 * 16 + (size_t)Mr * Mr * 4;
     if (lds > HAT_LDS_MAX) return HAT_ELDS;
-    auto kern = ocab_attn_kernel<T, NKT, KCH>;
+    auto kern = ocab_attn_kernel<T, NKT, KCH, SELF>;
     if (lds > 65536) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return (int)e;
     }
     dim3 grid(W / ws, H / ws, B * heads);
     HAT_LAUNCH(kern, grid, dim3(256), lds, s, reinterpret_cast<const T*>(q), reinterpret_cast<const T*>(kv), bias_rot,
-                       reinterpret_cast<T*>(out), H, W, C, heads, ws, wse, ldq, ldkv, ldo);
+                       reinterpret_cast<T*>(out), H, W, C, heads, ws, wse, ldq, ldkv, ldo, shift);
     return hat_check_launch();
 }
 
@@ -430,4 +450,26 @@ extern "C" int hat_ocab_attention(const void* q, const void* kv, const float* bi
     }
 #undef HAT_ATTN_CASE
     return HAT_EUNSUPPORTED;  // window sizes other than 16/24 and 8/12 are not instantiated
+}
+
+extern "C" int hat_window_attention(const void* q, const void* kv, const float* bias_flip, void* out, int32_t B, int32_t H,
+                                    int32_t W, int32_t C, int32_t heads, int32_t ws, int32_t shift, int32_t ldq,
+                                    int32_t ldkv, int32_t ldo, int32_t dtype, void* stream) {
+    if (!q || !kv || !bias_flip || !out || B < 1 || heads < 1 || C % heads) return HAT_EINVAL;
+    if (ws < 4 || ws % 4 || H % ws || W % ws || shift < 0 || shift >= ws || shift % 4) return HAT_EINVAL;
+    const int d = C / heads;
+    if (d > 32 || d % 2 || ldq < C || ldkv < 2 * C || ldo < C) return HAT_EINVAL;
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+#define HAT_WATTN_CASE(TT, N, K) return launch_attn<TT, N, K, true>(q, kv, bias_flip, out, B, H, W, C, heads, ws, ws, ldq, ldkv, ldo, s, shift)
+    if (dtype == HAT_BF16) {
+        if (ws == 16) HAT_WATTN_CASE(bf16_t, 16, 8);
+        if (ws == 8) HAT_WATTN_CASE(bf16_t, 4, 4);
+    } else if (dtype == HAT_F32) {
+        if (ws == 16) HAT_WATTN_CASE(float, 16, 8);
+        if (ws == 8) HAT_WATTN_CASE(float, 4, 4);
+    } else {
+        return HAT_EINVAL;
+    }
+#undef HAT_WATTN_CASE
+    return HAT_EUNSUPPORTED;  // window sizes other than 16 and 8 are not instantiated
 }

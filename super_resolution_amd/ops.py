@@ -207,6 +207,15 @@ def ocab_attention(q, kv, bias_rot, out, *, B: int, H: int, W: int, C_: int, hea
                                _stream()), "hat_ocab_attention"))
 
 
+def window_attention(q, kv, bias_flip, out, *, B: int, H: int, W: int, C_: int, heads: int, ws: int, shift: int, ldq: int,
+                     ldkv: int, ldo: int, dtype: int):
+    """(S)W-MSA core (hat_window_attention; swinir_arch.py:147-168 + roll / partition / mask / reverse :291-317)."""
+    lib = _lib.load()
+    _timed(f"ocab_attn_kernel<{_TNAME[dtype]}, self>", 2.0 * 2 * ws * ws * C_ * B * H * W, lambda: _lib.check(
+        lib.hat_window_attention(_ptr(q), _ptr(kv), _ptr(bias_flip), _ptr(out), B, H, W, C_, heads, ws, shift, ldq, ldkv, ldo,
+                                 dtype, _stream()), "hat_window_attention"))
+
+
 # ------------------------------------------------------------------------------------------------
 # fused feed-forward half of the HAB (hat_ffn)
 # ------------------------------------------------------------------------------------------------

@@ -29,3 +29,16 @@ def oracle_sd(name):
 
 def max_abs(a, b):
     return float((torch.as_tensor(a).double() - torch.as_tensor(b).double()).abs().max())
+
+
+WMSA_CASES = ["wmsa_c48_h2_ws16", "wmsa_c48_h6_ws8"]
+
+
+def wmsa_sd(C, heads, ws):
+    """Synthetic WindowAttention parameters: same keys / shapes / seeded generator as gen_golden_wmsa.py (the integer
+    relative_position_index is a deterministic function of ws and carries no randomness)."""
+    blank = {"relative_position_bias_table": torch.zeros((2 * ws - 1) ** 2, heads),
+             "relative_position_index": O.rpi_sa(ws),
+             "qkv.weight": torch.zeros(3 * C, C), "qkv.bias": torch.zeros(3 * C),
+             "proj.weight": torch.zeros(C, C), "proj.bias": torch.zeros(C)}
+    return synth.synth_state_dict(blank, W_SEED)

@@ -546,3 +546,65 @@ def test_aggr_with_folded_cab(geom):
                  x0=to_dev(x0, 16, tdt, dev), c_split=16, ldx0=16, r1=t.reshape(B, H * W, C).to(dev).contiguous(), ldr1=C)
     torch.cuda.synchronize()
     check(out.reshape(B, H, W, C), ref, dtype, "aggr + folded cab")
+
+
+# ------------------------------------------------------------------------------------------------
+# (S)W-MSA branch: hat_linear -> hat_window_attention -> hat_linear
+# ------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("dtype", DT)
+@pytest.mark.parametrize("name", ["wmsa_c48_h2_ws16", "wmsa_c48_h6_ws8"])
+def test_window_msa_vs_reference_golden(name, dtype):
+    """The product WindowAttention (same state-dict keys as swinir_arch.WindowAttention) against the outputs of the
+    reference's own module + roll / partition / mask / reverse, for W-MSA (shift 0) and SW-MSA (shift ws/2)."""
+    from helpers import golden, wmsa_sd
+    from super_resolution_amd.archs.window_msa import WindowAttention
+    dev = _dev()
+    g = golden(name + ".npz")
+    C, heads, ws, H, W = (int(v) for v in g["dims"])
+    m = WindowAttention(C, (ws, ws), heads, compute_dtype=dtype).eval()
+    m.load_state_dict(wmsa_sd(C, heads, ws), strict=True)
+    m = m.to(dev)
+    x = torch.from_numpy(g["x"]).to(dev)
+    for shift in (0, ws // 2):
+        y = m.forward_map(x, shift)
+        torch.cuda.synchronize()
+        check(y, torch.from_numpy(g[f"y_shift{shift}"]), dtype, f"{name} shift {shift}")
+    # reference call signature: pre-partitioned windows, no mask
+    xw = x.reshape(1, H // ws, ws, W // ws, ws, C).permute(0, 1, 3, 2, 4, 5).reshape(-1, ws * ws, C).contiguous()
+    yw = m(xw)
+    ref = torch.from_numpy(g["y_shift0"]).reshape(1, H // ws, ws, W // ws, ws, C).permute(0, 1, 3, 2, 4, 5).reshape(-1, ws * ws, C)
+    check(yw, ref, dtype, f"{name} windows")
+    with pytest.raises(NotImplementedError):
+        m(xw, mask=torch.zeros(1, ws * ws, ws * ws, device=dev))
+
+
+@pytest.mark.parametrize("dtype", DT)
+def test_window_msa_hats_shape_vs_oracle(dtype):
+    """C = 144, six heads of 24 (the HAT-S head geometry), B = 2, non-square frame, against the CPU oracle."""
+    from helpers import wmsa_sd
+    from super_resolution_amd.archs.window_msa import WindowAttention
+    dev = _dev()
+    C, heads, ws, B, H, W = 144, 6, 16, 2, 48, 32
+    sd = wmsa_sd(C, heads, ws)
+    m = WindowAttention(C, ws, heads, compute_dtype=dtype).eval()
+    m.load_state_dict(sd, strict=True)
+    m = m.to(dev)
+    x = rnd("wmsa144.x", (B, H, W, C))
+    for shift in (0, 8, 4):
+        ref = O.window_msa(x, {"a." + k: v for k, v in sd.items()}, "a", ws, heads, shift)
+        y = m.forward_map(x.to(dev), shift)
+        torch.cuda.synchronize()
+        check(y, ref, dtype, f"C144 shift {shift}")
+
+
+def test_window_attention_rejects_bad_arguments():
+    dev = _dev()
+    ops = _ops()
+    from super_resolution_amd._lib import HAT_F32
+    t = torch.zeros(1, 16, 16, 3 * 48, device=dev)
+    o = torch.zeros(1, 16, 16, 48, device=dev)
+    bias = torch.zeros(2, 31 * 31, device=dev)
+    kw = dict(B=1, H=16, W=16, C_=48, heads=2, ws=16, ldq=144, ldkv=144, ldo=48, dtype=HAT_F32)
+    for bad in (dict(shift=3), dict(shift=16), dict(H=24), dict(ws=12)):
+        with pytest.raises(RuntimeError):
+            ops.window_attention(t, t.view(-1)[48:], bias, o, **{**kw, "shift": 0, **bad})

@@ -9,7 +9,7 @@ import torch
 
 from oracle import hat_oracle as O
 from super_resolution_amd import synth
-from helpers import GOLDEN, W_SEED, X_SEED, cfg_of, golden, max_abs, oracle_sd
+from helpers import GOLDEN, W_SEED, WMSA_CASES, X_SEED, cfg_of, golden, max_abs, oracle_sd, wmsa_sd
 
 TOL = 1e-5  # restatement vs reference <= 1e-5 max-abs, fp32
 
@@ -114,3 +114,17 @@ def test_psnr_known_answers():
     t = torch.tensor([[[[0.5, 1.2], [-0.1, 0.25]]]]).repeat(1, 3, 1, 1)
     img = O.tensor2img_rgb(t)
     assert img.dtype == np.uint8 and img[0, 0, 0] == 128 and img[0, 1, 0] == 255 and img[1, 0, 0] == 0 and img[1, 1, 0] == 64
+
+
+@pytest.mark.parametrize("name", WMSA_CASES)
+def test_window_msa_vs_reference(name):
+    """Row f2: the (S)W-MSA restatement against the reference's WindowAttention + shift mask (swinir_arch.py)."""
+    g = golden(name + ".npz")
+    C, heads, ws, H, W = (int(v) for v in g["dims"])
+    sd = {"a." + k: v for k, v in wmsa_sd(C, heads, ws).items()}
+    x = torch.from_numpy(g["x"])
+    assert max_abs(x, synth.normal(X_SEED, name + ".x", (1, H, W, C))) == 0
+    assert torch.equal(O.sw_msa_mask(H, W, ws, ws // 2), torch.from_numpy(g["mask"]))
+    for shift in (0, ws // 2):
+        y = O.window_msa(x, sd, "a", ws, heads, shift)
+        assert max_abs(y, g[f"y_shift{shift}"]) <= TOL, shift
