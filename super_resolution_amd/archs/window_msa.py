@@ -90,17 +90,21 @@ class WindowAttention(nn.Module):
             raise RuntimeError(f"map {tuple(x.shape)} is not (B, k*{ws}, l*{ws}, {self.dim})")
         qkv_w, proj_w, bias_flip, dt = self._pack(x.device)
         tdt = ops.TORCH_DTYPE[dt]
+        ldc, ld3 = (C + 7) // 8 * 8, (3 * C + 7) // 8 * 8   # T-typed rows: channel stride rounded up to 8, zero pad channels
         with torch.no_grad():
-            xt = x.detach().to(tdt).contiguous()
-            qkv = torch.empty(B, H, W, 3 * C, dtype=tdt, device=x.device)
-            att = torch.empty(B, H, W, C, dtype=tdt, device=x.device)
-            out = torch.empty(B, H, W, C, dtype=tdt, device=x.device)
+            buf = torch.empty if ldc == C else torch.zeros   # pad channels must read as zeros
+            xt = buf(B, H, W, ldc, dtype=tdt, device=x.device)
+            xt[..., :C] = x.detach()
+            qkv = buf(B, H, W, ld3, dtype=tdt, device=x.device)
+            att = buf(B, H, W, ldc, dtype=tdt, device=x.device)
+            out = buf(B, H, W, ldc, dtype=tdt, device=x.device)
             run = lambda pw, src, dst, ldx, ldo: (ops.linear if pw.frag else ops.conv)(
                 pw, src, dst, B=B, H=H, W=W, dtype=dt, ldx=ldx, ldo=ldo, out_mode=O_NHWC_T)
-            run(qkv_w, xt, qkv, C, 3 * C)
+            run(qkv_w, xt, qkv, ldc, ld3)
             ops.window_attention(qkv, qkv.view(-1)[C:], bias_flip, att, B=B, H=H, W=W, C_=C, heads=self.num_heads, ws=ws,
-                                 shift=shift, ldq=3 * C, ldkv=3 * C, ldo=C, dtype=dt)
-            run(proj_w, att, out, C, C)
+                                 shift=shift, ldq=ld3, ldkv=ld3, ldo=ldc, dtype=dt)
+            run(proj_w, att, out, ldc, ldc)
+            out = out[..., :C]
         return out.to(x.dtype)
 
     def forward(self, x: torch.Tensor, mask=None) -> torch.Tensor:

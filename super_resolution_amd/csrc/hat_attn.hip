@@ -202,24 +202,56 @@ __device__ __forceinline__ float max3_raw(float a, float b, float c) {
 
 // D = 24 (C = 144) or 30 (C = 180, six heads): D = 30 pads K / Q to 32 channels (K rows of 4 XOR-swizzled slots), stages
 // and stores with 4-byte accesses (a head's 60-byte slice is only 4-byte aligned) and keeps the ones column at V[30].
-template <int D>
-__global__ __launch_bounds__(256, 2) void ocab_attn_fast_kernel(const bf16_t* __restrict__ q, const bf16_t* __restrict__ kv,
+// WSE = 24, SELF = false: OCAB (zero-padded 24 x 24 key window around the query window).  WSE = 16, SELF = true: (shifted-)
+// window self-attention for hat_window_attention — the key window is the query window, all coordinates live on the frame
+// shifted cyclically by `shift` (so every key is a real pixel), and in the last window row / column the -100 of the
+// shift mask is added to the scores of pairs in different mask bands.
+template <int D, int WSE, bool SELF>
+__global__ __launch_bounds__(256, WSE == 24 ? 2 : 4) void ocab_attn_fast_kernel(const bf16_t* __restrict__ q, const bf16_t* __restrict__ kv,
                                                                 const float* __restrict__ bias_rot, bf16_t* __restrict__ out,
-                                                                int H, int W, int C, int heads, int ldq, int ldkv, int ldo) {
+                                                                int B, int H, int W, int C, int heads, int ldq, int ldkv,
+                                                                int ldo, int shift) {
     using M = MT<bf16_t>;
     using frag_t = M::frag_t;
-    constexpr int WS = 16, WSE = 24, NK = 576, MR = 39, NKT = 36, KCH = 12, PAD = 4;
+    constexpr int WS = 16, NK = WSE * WSE, MR = WS + WSE - 1, NKT = NK / 16, KCH = WSE == 24 ? 12 : 8, PAD = (WSE - WS) / 2;
+    constexpr int CH_ROWS = KCH * 16 / WSE;  // key rows per chunk (8 for both geometries)
+    static_assert(!SELF || WSE == WS, "self-attention windows coincide with the query windows");
     constexpr int KR = D == 24 ? 24 : 32;   // K row length in LDS (elements)
     constexpr int ONE = D == 24 ? 24 : 30;  // V column that holds 1.0 (the softmax denominator row of O^T)
     constexpr float LOG2E = 1.4426950408889634f;
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    bf16_t* Ks = reinterpret_cast<bf16_t*>(smem);                 // [576][24]
-    bf16_t* Vs = Ks + NK * KR;                                    // [576][32]: D channels, 1.0, zeros
-    float* tab = reinterpret_cast<float*>(Vs + NK * 32);          // [39*39]
+    bf16_t* Ks = reinterpret_cast<bf16_t*>(smem);                 // [NK][KR]
+    bf16_t* Vs = Ks + NK * KR;                                    // [NK][32]: D channels, 1.0, zeros
+    float* tab = reinterpret_cast<float*>(Vs + NK * 32);          // [MR*MR]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = lane >> 4, c16 = lane & 15;
-    const int wx = blockIdx.x, wy = blockIdx.y;
-    const int b = blockIdx.z / heads, h = blockIdx.z - b * heads;
+    // Workgroups are dealt round-robin to the 8 XCDs, each with its own L2.  A head reads a 2D-byte slice of every q / k / v
+    // row, i.e. part of a cache line that the window's other heads need too: block L -> XCD L % 8, and inside an XCD
+    // consecutive blocks are the heads of ONE window, so the lines are fetched from HBM once and hit in that XCD's L2
+    // (with the head as the slowest grid index every head re-fetched them: 0.82 -> 0.43 ms for W-MSA, 0.97 -> 0.88 ms for
+    // OCAB at 720p; giving each XCD a contiguous range of windows instead of every 8th one measured no better).
+    const int nwx = W / WS, nwy = H / WS;
+    const int xj = (int)blockIdx.x >> 3;
+    const int widx = (xj / heads) * 8 + ((int)blockIdx.x & 7), h = xj % heads;
+    if (widx >= B * nwx * nwy) return;   // whole workgroup, before any barrier
+    const int b = widx / (nwx * nwy), wrem = widx - b * nwx * nwy;
+    const int wy = wrem / nwx, wx = wrem - wy * nwx;
     const size_t img = (size_t)b * H * W;
+    // window position (row, col) -> pixel of the map: identity for OCAB queries, cyclic shift for SELF
+    auto qpixel = [&](int row, int col) {
+        int y = wy * WS + row, x = wx * WS + col;
+        if (SELF) {
+            y += shift; if (y >= H) y -= H;
+            x += shift; if (x >= W) x -= W;
+        }
+        return img + (size_t)y * W + x;
+    };
+    // key (kh, kw) of the key window -> clamped pixel and whether it is a real one (SELF: always, after the wrap)
+    auto kpixel = [&](int kh, int kw, bool& inb) {
+        if (SELF) { inb = true; return qpixel(kh, kw); }
+        const int y = wy * WS - PAD + kh, x = wx * WS - PAD + kw;
+        inb = y >= 0 && y < H && x >= 0 && x < W;
+        return img + (size_t)min(max(y, 0), H - 1) * W + min(max(x, 0), W - 1);
+    };
 
     frag_t qfr[4];   // this wave's four query tiles: query tile qt = window row qt, lane c16 = window column
     constexpr int NTAB = (MR * MR + 255) / 256;
@@ -234,7 +266,7 @@ __global__ __launch_bounds__(256, 2) void ocab_attn_fast_kernel(const bf16_t* __
         // load a clamped pixel and are zeroed by a select), so the phase costs one memory latency, not nine.
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-            const size_t qpix = img + (size_t)(wy * WS + wave + 4 * i) * W + (wx * WS + c16);
+            const size_t qpix = qpixel(wave + 4 * i, c16);
             qfr[i] = M::load(q + qpix * ldq + h * D + 8 * (g < 3 ? g : 2));
             if (g == 3) qfr[i] = M::zero();
         }
@@ -245,9 +277,8 @@ __global__ __launch_bounds__(256, 2) void ocab_attn_fast_kernel(const bf16_t* __
             const int i = tid + it * 256;
             const int key = i >> 2, c = i & 3;
             const int kh = key / WSE, kw = key - kh * WSE;
-            const int y = wy * WS - PAD + kh, x = wx * WS - PAD + kw;
-            const int yc = min(max(y, 0), H - 1), xc = min(max(x, 0), W - 1);
-            const bf16_t* p = kv + (img + (size_t)yc * W + xc) * ldkv + h * D + 8 * (c < 3 ? c : 2);
+            bool inb;
+            const bf16_t* p = kv + kpixel(kh, kw, inb) * ldkv + h * D + 8 * (c < 3 ? c : 2);
             kq[it] = *reinterpret_cast<const u32x4*>(p);
             vq[it] = *reinterpret_cast<const u32x4*>(p + C);
         }
@@ -256,8 +287,8 @@ __global__ __launch_bounds__(256, 2) void ocab_attn_fast_kernel(const bf16_t* __
             const int i = tid + it * 256;
             const int key = i >> 2, c = i & 3;
             const int kh = key / WSE, kw = key - kh * WSE;
-            const int y = wy * WS - PAD + kh, x = wx * WS - PAD + kw;
-            const bool inb = y >= 0 && y < H && x >= 0 && x < W;
+            bool inb;
+            (void)kpixel(kh, kw, inb);
             const int vsw = (key >> 1) & 2;  // rows 4..7 of every 8 swap their 32-byte halves: transposed reads stay conflict-free
             const u32x4 zero = {0u, 0u, 0u, 0u};
             // channel 24 = 1.0 for EVERY key (out-of-image keys still count in the softmax denominator)
@@ -269,7 +300,7 @@ __global__ __launch_bounds__(256, 2) void ocab_attn_fast_kernel(const bf16_t* __
         // 4-byte staging: dword dw (two channels) of key `key`; dword 15 is the pad of K and [1.0, 0] of V
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-            const size_t qpix = img + (size_t)(wy * WS + wave + 4 * i) * W + (wx * WS + c16);
+            const size_t qpix = qpixel(wave + 4 * i, c16);
             const unsigned* qp = reinterpret_cast<const unsigned*>(q + qpix * ldq + h * D) + 4 * g;
             u32x4 v;
 #pragma unroll
@@ -277,7 +308,8 @@ __global__ __launch_bounds__(256, 2) void ocab_attn_fast_kernel(const bf16_t* __
             if (g == 3) v[3] = 0u;   // channels 30, 31
             qfr[i] = __builtin_bit_cast(frag_t, v);
         }
-        constexpr int BATCH = 12, NPASS = NK * 16 / 256 / BATCH;
+        constexpr int BATCH = WSE == 24 ? 12 : 8, NPASS = NK * 16 / 256 / BATCH;
+        static_assert(NPASS * BATCH * 256 == NK * 16, "staging passes must cover the key window exactly");
         unsigned* Kd = reinterpret_cast<unsigned*>(Ks);
         unsigned* Vd = reinterpret_cast<unsigned*>(Vs);
         for (int ps = 0; ps < NPASS; ++ps) {
@@ -287,9 +319,8 @@ __global__ __launch_bounds__(256, 2) void ocab_attn_fast_kernel(const bf16_t* __
                 const int i = tid + (ps * BATCH + it) * 256;
                 const int key = i >> 4, dw = i & 15;
                 const int kh = key / WSE, kw = key - kh * WSE;
-                const int y = wy * WS - PAD + kh, x = wx * WS - PAD + kw;
-                const int yc = min(max(y, 0), H - 1), xc = min(max(x, 0), W - 1);
-                const unsigned* p = reinterpret_cast<const unsigned*>(kv + (img + (size_t)yc * W + xc) * ldkv + h * D) + min(dw, D / 2 - 1);
+                bool inb;
+                const unsigned* p = reinterpret_cast<const unsigned*>(kv + kpixel(kh, kw, inb) * ldkv + h * D) + min(dw, D / 2 - 1);
                 kq[it] = p[0];
                 vq[it] = p[C / 2];
             }
@@ -298,8 +329,8 @@ __global__ __launch_bounds__(256, 2) void ocab_attn_fast_kernel(const bf16_t* __
                 const int i = tid + (ps * BATCH + it) * 256;
                 const int key = i >> 4, dw = i & 15;
                 const int kh = key / WSE, kw = key - kh * WSE;
-                const int y = wy * WS - PAD + kh, x = wx * WS - PAD + kw;
-                const bool inb = y >= 0 && y < H && x >= 0 && x < W;
+                bool inb;
+                (void)kpixel(kh, kw, inb);
                 const int slot = dw >> 2, vsw = (key >> 1) & 2, ksw = (key >> 1) & 3;
                 Kd[key * 16 + 4 * (slot ^ ksw) + (dw & 3)] = (inb && dw < D / 2) ? kq[it] : 0u;
                 Vd[key * 16 + 4 * (slot ^ vsw) + (dw & 3)] = dw == 15 ? 0x00003F80u : (inb ? vq[it] : 0u);
@@ -314,8 +345,8 @@ __global__ __launch_bounds__(256, 2) void ocab_attn_fast_kernel(const bf16_t* __
     __syncthreads();
 
     const int trq = c16 >> 2, trp = c16 & 3;  // this lane's address role inside its 16-lane transpose group
-    // Bias-table offsets of this lane's 4 keys (rows 4g..4g+3 of key tile t; 24 % 4 == 0 keeps them in one key
-    // row) against query column c16 of window row 0.  A chunk of 12 key tiles is exactly 8 key rows and a query
+    // Bias-table offsets of this lane's 4 keys (rows 4g..4g+3 of key tile t; WSE % 4 == 0 keeps them in one key
+    // row) against query column c16 of window row 0.  A chunk of KCH key tiles is exactly 8 key rows and a query
     // tile is exactly one window row, so chunk ch / query tile qt only add the uniform (8 * ch - qt) * MR.
     int toff[KCH];
 #pragma unroll
@@ -327,7 +358,7 @@ __global__ __launch_bounds__(256, 2) void ocab_attn_fast_kernel(const bf16_t* __
 #pragma unroll
     for (int qi4 = 0; qi4 < 4; ++qi4) {
         const int qt = wave + 4 * qi4;
-        const size_t qpix = img + (size_t)(wy * WS + qt) * W + (wx * WS + c16);
+        const size_t qpix = qpixel(qt, c16);
         const frag_t qf = qfr[qi4];
         // D = 24: lanes g == 3 meet a zero Q fragment and re-read group 2; D = 30: 4 slots per row, XOR-swizzled by the row
         const bf16_t* krow = D == 24 ? Ks + c16 * KR + (g < 3 ? 8 * g : 16) : Ks + c16 * KR + 8 * (g ^ ((c16 >> 1) & 3));
@@ -336,7 +367,7 @@ __global__ __launch_bounds__(256, 2) void ocab_attn_fast_kernel(const bf16_t* __
 #pragma unroll 1
         for (int ch = 0; ch < NKT / KCH; ++ch) {
             const int kt0 = ch * KCH;
-            const float* tbase = tab + (8 * ch - qt) * MR;
+            const float* tbase = tab + (CH_ROWS * ch - qt) * MR;
             f32x4 s[KCH];
 #pragma unroll
             for (int t = 0; t < KCH; ++t) {
@@ -344,6 +375,21 @@ __global__ __launch_bounds__(256, 2) void ocab_attn_fast_kernel(const bf16_t* __
                 const f32x4 bias4 = {tb[0], tb[1], tb[2], tb[3]};
                 const frag_t kf = M::load(krow + (kt0 + t) * 16 * KR);
                 s[t] = M::mma(kf, qf, bias4);
+            }
+            if constexpr (SELF) {
+                // Shift mask (swinir_arch.py:262-280): bands [0, n-ws), [n-ws, n-shift), [n-shift, n) of the shifted frame,
+                // so only the last window row / column mixes bands.  Key tile t is key row kt0 + t, the query tile is
+                // query row qt (both wave-uniform); the lane's 4 key columns 4g.. share a band (shift % 4 == 0).
+                const bool lastr = wy == nwy - 1, lastc = wx == nwx - 1;
+                if (shift > 0 && (lastr || lastc)) {
+                    const float xm = (lastc && ((4 * g >= WS - shift) != (c16 >= WS - shift))) ? -100.0f : 0.0f;
+#pragma unroll
+                    for (int t = 0; t < KCH; ++t) {
+                        const bool ydiff = lastr && ((kt0 + t >= WS - shift) != (qt >= WS - shift));
+                        const float madd = ydiff ? -100.0f : xm;
+                        s[t][0] += madd; s[t][1] += madd; s[t][2] += madd; s[t][3] += madd;
+                    }
+                }
             }
             float mx = -3.0e38f;
 #pragma unroll
@@ -430,11 +476,12 @@ extern "C" int hat_ocab_attention(const void* q, const void* kv, const float* bi
     const bool fast30 = d == 30 && ldq % 2 == 0 && ldkv % 2 == 0 && ldo % 2 == 0 && C % 2 == 0;
     if (dtype == HAT_BF16 && ws == 16 && wse == 24 && (fast24 || fast30)) {
         const size_t lds = (size_t)576 * (fast24 ? 24 : 32) * 2 + (size_t)576 * 32 * 2 + (size_t)39 * 39 * 4;
-        auto kern = fast24 ? ocab_attn_fast_kernel<24> : ocab_attn_fast_kernel<30>;
+        auto kern = fast24 ? ocab_attn_fast_kernel<24, 24, false> : ocab_attn_fast_kernel<30, 24, false>;
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return (int)e;
-        HAT_LAUNCH(kern, dim3(W / ws, H / ws, B * heads), dim3(256), lds, s, reinterpret_cast<const bf16_t*>(q),
-                   reinterpret_cast<const bf16_t*>(kv), bias_rot, reinterpret_cast<bf16_t*>(out), H, W, C, heads, ldq, ldkv, ldo);
+        const int nwin = B * (W / ws) * (H / ws);
+        HAT_LAUNCH(kern, dim3((nwin + 7) / 8 * 8 * heads), dim3(256), lds, s, reinterpret_cast<const bf16_t*>(q),
+                   reinterpret_cast<const bf16_t*>(kv), bias_rot, reinterpret_cast<bf16_t*>(out), B, H, W, C, heads, ldq, ldkv, ldo, 0);
         return hat_check_launch();
     }
     const int nkt = wse * wse / 16;
@@ -460,6 +507,18 @@ extern "C" int hat_window_attention(const void* q, const void* kv, const float* 
     const int d = C / heads;
     if (d > 32 || d % 2 || ldq < C || ldkv < 2 * C || ldo < C) return HAT_EINVAL;
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    const bool fast24 = d == 24 && ldq % 8 == 0 && ldkv % 8 == 0 && ldo % 4 == 0 && C % 8 == 0 &&
+                        (reinterpret_cast<uintptr_t>(q) | reinterpret_cast<uintptr_t>(kv)) % 16 == 0 && reinterpret_cast<uintptr_t>(out) % 8 == 0;
+    const bool fast30 = d == 30 && ldq % 2 == 0 && ldkv % 2 == 0 && ldo % 2 == 0 && C % 2 == 0;
+    if (dtype == HAT_BF16 && ws == 16 && (fast24 || fast30)) {
+        const size_t lds = (size_t)256 * (fast24 ? 24 : 32) * 2 + (size_t)256 * 32 * 2 + (size_t)31 * 31 * 4;
+        auto kern = fast24 ? ocab_attn_fast_kernel<24, 16, true> : ocab_attn_fast_kernel<30, 16, true>;
+        const int nwin = B * (W / ws) * (H / ws);
+        HAT_LAUNCH(kern, dim3((nwin + 7) / 8 * 8 * heads), dim3(256), lds, s, reinterpret_cast<const bf16_t*>(q),
+                   reinterpret_cast<const bf16_t*>(kv), bias_flip, reinterpret_cast<bf16_t*>(out), B, H, W, C, heads, ldq, ldkv,
+                   ldo, shift);
+        return hat_check_launch();
+    }
 #define HAT_WATTN_CASE(TT, N, K) return launch_attn<TT, N, K, true>(q, kv, bias_flip, out, B, H, W, C, heads, ws, ws, ldq, ldkv, ldo, s, shift)
     if (dtype == HAT_BF16) {
         if (ws == 16) HAT_WATTN_CASE(bf16_t, 16, 8);

@@ -579,22 +579,25 @@ def test_window_msa_vs_reference_golden(name, dtype):
 
 
 @pytest.mark.parametrize("dtype", DT)
-def test_window_msa_hats_shape_vs_oracle(dtype):
-    """C = 144, six heads of 24 (the HAT-S head geometry), B = 2, non-square frame, against the CPU oracle."""
+@pytest.mark.parametrize("geom", [(144, 6, 2, 48, 32), (180, 6, 1, 32, 48), (60, 2, 1, 16, 32)], ids=["C144_d24", "C180_d30", "C60_d30_one_row"])
+def test_window_msa_shipped_head_sizes_vs_oracle(geom, dtype):
+    """Head sizes of the shipped variants (24 for C = 144, 30 for C = 180: the bf16 fast kernels), B = 2, non-square
+    frames, a frame of a single window row, shifts 0 / 8 / 4 — against the CPU oracle."""
     from helpers import wmsa_sd
     from super_resolution_amd.archs.window_msa import WindowAttention
     dev = _dev()
-    C, heads, ws, B, H, W = 144, 6, 16, 2, 48, 32
+    C, heads, B, H, W = geom
+    ws = 16
     sd = wmsa_sd(C, heads, ws)
     m = WindowAttention(C, ws, heads, compute_dtype=dtype).eval()
     m.load_state_dict(sd, strict=True)
     m = m.to(dev)
-    x = rnd("wmsa144.x", (B, H, W, C))
+    x = rnd(f"wmsa{C}.x", (B, H, W, C))
     for shift in (0, 8, 4):
         ref = O.window_msa(x, {"a." + k: v for k, v in sd.items()}, "a", ws, heads, shift)
         y = m.forward_map(x.to(dev), shift)
         torch.cuda.synchronize()
-        check(y, ref, dtype, f"C144 shift {shift}")
+        check(y, ref, dtype, f"C{C} shift {shift}")
 
 
 def test_window_attention_rejects_bad_arguments():
