@@ -12,6 +12,8 @@
 //   K is flat: k = tap * Cin_p + ci; a lane's 8-element k group never straddles a tap because
 //   Cin_p % 8 == 0, so each lane tracks its own (tap, ci) and reads its B fragment from the
 //   shifted pixel: no im2col buffer exists anywhere.
+#include <type_traits>
+
 #include "hat_common.h"
 
 namespace {
@@ -101,57 +103,67 @@ __global__ __launch_bounds__(WAVES * 64) void conv_kernel(const HatConvDesc d) {
         const int total = npixh * ppp;
         // SU pieces per thread per pass, every load unconditional (clamped address, zero selected afterwards): a load
         // under a lane mask is waited for where it is issued, which made this loop one memory round trip per piece
-        constexpr int SU = 6;
-        for (int i0 = tid; i0 < total; i0 += NTHR * SU) {
-            u32x4 v[SU];
-            bool ok[SU];
+        // (13 in flight when the tile needs more than 6 per thread: the CAB squeeze conv's tile is 13 pieces per thread and
+        // its K loop is short, so each extra round trip of staging showed directly in its time)
+        auto stage = [&](auto su_tag) {
+            constexpr int SU = decltype(su_tag)::value;
+            for (int i0 = tid; i0 < total; i0 += NTHR * SU) {
+                u32x4 v[SU];
+                bool ok[SU];
 #pragma unroll
-            for (int u = 0; u < SU; ++u) {
-                const int i = min(i0 + u * NTHR, total - 1);
-                const int q = i / ppp, c = (i - q * ppp) * VEC;
-                const int qy = q / TWH, qx = q - qy * TWH;
-                const int y = y0 - hl + qy, x = x0 - hl + qx;
-                ok[u] = y >= 0 && y < H && x >= 0 && x < W && c < Cin;
-                const size_t pix = ((size_t)b * H + min(max(y, 0), H - 1)) * W + min(max(x, 0), W - 1);
-                const T* src = (xg0 != nullptr && c < d.c_split) ? xg0 + pix * d.ldx0 + c : xg + pix * d.ldx + c;
-                v[u] = *reinterpret_cast<const u32x4*>(src);
-            }
-#pragma unroll
-            for (int u = 0; u < SU; ++u) {
-                const int i = i0 + u * NTHR;
-                if (i < total) {
+                for (int u = 0; u < SU; ++u) {
+                    const int i = min(i0 + u * NTHR, total - 1);
                     const int q = i / ppp, c = (i - q * ppp) * VEC;
-                    *reinterpret_cast<u32x4*>(Xs + (size_t)q * ldxs + c) = ok[u] ? v[u] : u32x4{0u, 0u, 0u, 0u};
+                    const int qy = q / TWH, qx = q - qy * TWH;
+                    const int y = y0 - hl + qy, x = x0 - hl + qx;
+                    ok[u] = y >= 0 && y < H && x >= 0 && x < W && c < Cin;
+                    const size_t pix = ((size_t)b * H + min(max(y, 0), H - 1)) * W + min(max(x, 0), W - 1);
+                    const T* src = (xg0 != nullptr && c < d.c_split) ? xg0 + pix * d.ldx0 + c : xg + pix * d.ldx + c;
+                    v[u] = *reinterpret_cast<const u32x4*>(src);
+                }
+#pragma unroll
+                for (int u = 0; u < SU; ++u) {
+                    const int i = i0 + u * NTHR;
+                    if (i < total) {
+                        const int q = i / ppp, c = (i - q * ppp) * VEC;
+                        *reinterpret_cast<u32x4*>(Xs + (size_t)q * ldxs + c) = ok[u] ? v[u] : u32x4{0u, 0u, 0u, 0u};
+                    }
                 }
             }
-        }
+        };
+        if (total > NTHR * 6) stage(std::integral_constant<int, 13>{});
+        else stage(std::integral_constant<int, 6>{});
     } else if (d.x_mode == HAT_X_NHWC_F32) {
         const float* xg = reinterpret_cast<const float*>(d.x);
         const int gpp = Cin_p / 4;
         const int total = npixh * gpp;
-        constexpr int SU = 6;  // see the bf16/T branch above
-        for (int i0 = tid; i0 < total; i0 += NTHR * SU) {
-            f32x4 v[SU];
-            bool ok[SU];
+        auto stage = [&](auto su_tag) {   // see the bf16/T branch above
+            constexpr int SU = decltype(su_tag)::value;
+            for (int i0 = tid; i0 < total; i0 += NTHR * SU) {
+                f32x4 v[SU];
+                bool ok[SU];
 #pragma unroll
-            for (int u = 0; u < SU; ++u) {
-                const int i = min(i0 + u * NTHR, total - 1);
-                const int q = i / gpp, c = (i - q * gpp) * 4;
-                const int qy = q / TWH, qx = q - qy * TWH;
-                const int y = y0 - hl + qy, x = x0 - hl + qx;
-                ok[u] = y >= 0 && y < H && x >= 0 && x < W && c < Cin;
-                const size_t pix = ((size_t)b * H + min(max(y, 0), H - 1)) * W + min(max(x, 0), W - 1);
-                v[u] = *reinterpret_cast<const f32x4*>(xg + pix * d.ldx + min(c, Cin - 4));
-            }
-#pragma unroll
-            for (int u = 0; u < SU; ++u) {
-                const int i = i0 + u * NTHR;
-                if (i < total) {
+                for (int u = 0; u < SU; ++u) {
+                    const int i = min(i0 + u * NTHR, total - 1);
                     const int q = i / gpp, c = (i - q * gpp) * 4;
-                    Vec4<T>::store(Xs + (size_t)q * ldxs + c, ok[u] ? v[u] : f32x4{0.f, 0.f, 0.f, 0.f});
+                    const int qy = q / TWH, qx = q - qy * TWH;
+                    const int y = y0 - hl + qy, x = x0 - hl + qx;
+                    ok[u] = y >= 0 && y < H && x >= 0 && x < W && c < Cin;
+                    const size_t pix = ((size_t)b * H + min(max(y, 0), H - 1)) * W + min(max(x, 0), W - 1);
+                    v[u] = *reinterpret_cast<const f32x4*>(xg + pix * d.ldx + min(c, Cin - 4));
+                }
+#pragma unroll
+                for (int u = 0; u < SU; ++u) {
+                    const int i = i0 + u * NTHR;
+                    if (i < total) {
+                        const int q = i / gpp, c = (i - q * gpp) * 4;
+                        Vec4<T>::store(Xs + (size_t)q * ldxs + c, ok[u] ? v[u] : f32x4{0.f, 0.f, 0.f, 0.f});
+                    }
                 }
             }
-        }
+        };
+        if (total > NTHR * 6) stage(std::integral_constant<int, 12>{});
+        else stage(std::integral_constant<int, 6>{});
     } else {  // HAT_X_NCHW_F32_MEAN: (x - mean[c]) * in_scale, zero padding applied AFTER the shift
         const float* xg = reinterpret_cast<const float*>(d.x);
         const int total = npixh * Cin_p;
