@@ -116,6 +116,25 @@ template <> struct Vec4<bf16_t> {
     }
 };
 
+// Two adjacent n-tiles' accumulators of one pixel -> ONE 16-byte bf16 store per lane.  In the MFMA D layout lane group g
+// holds channels 4g..4g+3 of every n-tile, so a plain store is 8 bytes per lane and 32 contiguous bytes per pixel.
+// v_permlane16_swap exchanges the odd 16-lane rows of its first operand with the even rows of its second: afterwards an
+// even lane group holds 8 consecutive channels of tile `nt`, an odd one 8 consecutive channels of tile `nt + 1`, and one
+// store instruction writes 64 contiguous bytes per pixel.  All 64 lanes must be active.  `row` = the pixel's output row,
+// n0 = first channel of tile nt; needs 16-byte aligned rows.
+__device__ __forceinline__ void store_pair_bf16(bf16_t* row, int n0, int g, f32x4 a, f32x4 b) {
+    typedef bf16_t v4 __attribute__((ext_vector_type(4)));
+    typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+    const v4 ha = {(bf16_t)a[0], (bf16_t)a[1], (bf16_t)a[2], (bf16_t)a[3]};
+    const v4 hb = {(bf16_t)b[0], (bf16_t)b[1], (bf16_t)b[2], (bf16_t)b[3]};
+    const u32x2 ua = __builtin_bit_cast(u32x2, ha), ub = __builtin_bit_cast(u32x2, hb);
+    const auto r0 = __builtin_amdgcn_permlane16_swap(ua[0], ub[0], false, false);
+    const auto r1 = __builtin_amdgcn_permlane16_swap(ua[1], ub[1], false, false);
+    const u32x4 v = {r0[0], r1[0], r0[1], r1[1]};
+    const int n = (g & 1) ? n0 + 16 + 4 * (g - 1) : n0 + 4 * g;
+    *reinterpret_cast<u32x4*>(row + n) = v;
+}
+
 // LDS row stride (in elements) for rows of `n` elements of size `es`, for MFMA operand images read by ds_read_b128
 // with lane (c16, g) -> row base + c16, 16-byte slot k0 + g (bf16) or k0 + 2g (+1) (f32).  The instruction is serviced
 // in the lane groups {0-3,12-15,20-27}, {4-11,16-19,28-31}, {32-35,...}: rows 0-3 and 12-15 of lane group g together

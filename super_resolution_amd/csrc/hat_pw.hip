@@ -184,7 +184,13 @@ __global__ __launch_bounds__(WAVES * 64, MINW) void pw_kernel(const HatConvDesc 
                 bcur[ks] = bnxt[ks];
                 if constexpr (DEEP) bnxt[ks] = bnx2[ks];
             }
-            if (SPEC || p < npix_total) {
+            if constexpr (SPEC && !Tag::outf32 && sizeof(T) == 2) {
+                // full tiles, bf16 rows: n-tiles leave in pairs, 16 bytes per lane (store_pair_bf16)
+                bf16_t* orow = reinterpret_cast<bf16_t*>(d.out) + pc * d.ldo;
+#pragma unroll
+                for (int nt = 0; nt + 1 < NT; nt += 2) store_pair_bf16(orow, nt * 16, g, acc[nt], acc[nt + 1]);
+                if constexpr (NT & 1) Vec4<T>::store(reinterpret_cast<T*>(d.out) + pc * d.ldo + (NT - 1) * 16 + 4 * g, acc[NT - 1]);
+            } else if (SPEC || p < npix_total) {
                 const long ps = SPEC ? pc : p;
 #pragma unroll
                 for (int nt = 0; nt < NT; ++nt) {
@@ -216,7 +222,21 @@ __global__ __launch_bounds__(WAVES * 64, MINW) void pw_kernel(const HatConvDesc 
                     }
                     qq += __shfl_xor(qq, 16); qq += __shfl_xor(qq, 32);
                     const float rstd = 1.0f / sqrtf(qq / (float)C + 1e-5f);
-                    if (SPEC || p < npix_total) {
+                    auto ln_val = [&](int nt) {
+                        const int n = nt * 16 + 4 * g;
+                        const f32x4 gm = *reinterpret_cast<const f32x4*>(lnp + n);
+                        const f32x4 bt = *reinterpret_cast<const f32x4*>(lnp + NT * 16 + n);
+                        f32x4 o;
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) o[r] = (acc[nt][r] - mean) * rstd * gm[r] + bt[r];
+                        return o;
+                    };
+                    if constexpr (SPEC && sizeof(T) == 2) {   // full tiles: 16-byte stores of n-tile pairs
+                        bf16_t* lo = reinterpret_cast<bf16_t*>(d.ln_out) + pc * d.ld_ln;
+#pragma unroll
+                        for (int nt = 0; nt + 1 < NT; nt += 2) store_pair_bf16(lo, nt * 16, g, ln_val(nt), ln_val(nt + 1));
+                        if constexpr (NT & 1) Vec4<T>::store(reinterpret_cast<T*>(d.ln_out) + pc * d.ld_ln + (NT - 1) * 16 + 4 * g, ln_val(NT - 1));
+                    } else if (SPEC || p < npix_total) {
                         T* lo = reinterpret_cast<T*>(d.ln_out) + (SPEC ? pc : p) * d.ld_ln;
 #pragma unroll
                         for (int nt = 0; nt < NT; ++nt) {
@@ -248,14 +268,17 @@ __global__ __launch_bounds__(WAVES * 64, MINW) void pw_kernel(const HatConvDesc 
     // specialised copies need: one slice that stores all NT*16 channels, no split source oddities beyond load_b's, and
     // (with r2) the scale table in LDS
     const bool full = d.n_slices == 1 && d.n_store == NT * 16;
+    // T-typed rows leave the specialised copies in 16-byte pieces (store_pair_bf16)
+    const bool out16 = d.ldo % 8 == 0 && reinterpret_cast<uintptr_t>(d.out) % 16 == 0;
+    const bool ln16 = d.ld_ln % 8 == 0 && reinterpret_cast<uintptr_t>(d.ln_out) % 16 == 0;
     if constexpr (RES) {
         const bool f32o = d.out_mode == HAT_O_NHWC_F32;
         if (full && f32o && d.r1 && d.r2 && scale_in_lds && !emit_ln) tile_loop(PwTag<true, true, true, true, false>{});
-        else if (full && f32o && d.r1 && !d.r2 && emit_ln && !d.ln_ones) tile_loop(PwTag<true, true, false, true, true>{});
+        else if (full && f32o && d.r1 && !d.r2 && emit_ln && !d.ln_ones && ln16) tile_loop(PwTag<true, true, false, true, true>{});
         else if (full && f32o && d.r1 && !d.r2 && !emit_ln) tile_loop(PwTag<true, true, false, true, false>{});
         else tile_loop(PwTag<false, false, false, false, false>{});
     } else {
-        if (full && d.out_mode == HAT_O_NHWC_T) tile_loop(PwTag<true, false, false, false, false>{});
+        if (full && d.out_mode == HAT_O_NHWC_T && out16) tile_loop(PwTag<true, false, false, false, false>{});
         else tile_loop(PwTag<false, false, false, false, false>{});
     }
 }
