@@ -162,3 +162,40 @@ def test_headline_size_720p_properties():
     torch.cuda.synchronize()
     d = (yc[:, :, :512] - y32[:, :, :512]).abs()
     assert float(d.mean()) < 0.05 * float(y32[:, :, :512].abs().mean()) + 1e-3
+
+
+def test_cfg3_hatl_512_properties():
+    """BASELINE config 3 (HAT-L x4, 3x512x512) at full size — beyond what the CPU oracle finishes in seconds, so
+    size-independent properties: shape, finiteness, bit-reproducibility, and the bf16 path within the stated bf16
+    tolerance (>= 40 dB) of this build's own fp32 path."""
+    dev = _dev()
+    x = synth.synth_input(X_SEED, (1, 3, 512, 512)).to(dev)
+    net16 = build_net("HAT-L_x4", "bf16", dev)
+    y = net16(x).clone()
+    y2 = net16(x)
+    torch.cuda.synchronize()
+    assert y.shape == (1, 3, 2048, 2048) and torch.isfinite(y).all()
+    assert torch.equal(y, y2)
+    del y2, net16
+    y32 = build_net("HAT-L_x4", "f32", dev)(x)
+    torch.cuda.synchronize()
+    assert torch.isfinite(y32).all()
+    psnr = 10 * np.log10(1.0 / float(((y.double() - y32.double()) ** 2).mean()))
+    assert psnr >= 40.0, f"bf16 vs fp32 path, HAT-L 512x512: {psnr:.2f} dB"
+
+
+def test_cfg5_hatl_batch32_samples_are_independent():
+    """BASELINE config 5 (HAT-L x4, batch 32 of 3x256x256, bf16) at full size.  Every sample has its own ECA pooling and
+    its own dynamic ESC kernel (the reference itself only supports B = 1 there), so sample i of the batch must
+    equal the same image run alone; checked for the first, a middle and the last sample."""
+    dev = _dev()
+    net = build_net("HAT-L_x4", "bf16", dev)
+    x = synth.synth_input(X_SEED, (32, 3, 256, 256)).to(dev)
+    y = net(x)
+    torch.cuda.synchronize()
+    assert y.shape == (32, 3, 1024, 1024) and torch.isfinite(y).all()
+    for i in (0, 13, 31):
+        yi = net(x[i:i + 1].contiguous())
+        torch.cuda.synchronize()
+        err = max_abs(y[i:i + 1], yi)
+        assert err <= 1e-6, f"sample {i}: batch vs alone differ by {err:.3e}"
