@@ -110,6 +110,11 @@ __global__ __launch_bounds__(WAVES * 64, MINW) void pw_kernel(const HatConvDesc 
         const bool out_f32 = SPEC ? Tag::outf32 : (d.out_mode != HAT_O_NHWC_T);
         const bool do_ln = SPEC ? Tag::ln : emit_ln;
         const bool sc_lds = SPEC ? true : (scale_in_lds != 0);
+        // The last n-tile may be partial (C = 180 = 11.25 tiles).  The specialised copies stay free of control flow: a lane
+        // group past the last channel loads its residual from, and re-stores, ITS OWN channels of the previous n-tile (same
+        // address, same value as the store it already made), chosen with selects.  Only the fp32-output residual copies
+        // are entered with a partial tile (`tail_ok` below).
+        const bool lastok = !SPEC || 4 * g < d.n_store - (NT - 1) * 16;
         long tile = tile0;
         // Software pipeline, ordered around how hipcc places its waits.  Its s_waitcnt bookkeeping is merged at the loop
         // header with the (store-free) loop entry state, so every in-loop wait on a load degenerates to "wait for
@@ -122,7 +127,8 @@ __global__ __launch_bounds__(WAVES * 64, MINW) void pw_kernel(const HatConvDesc 
                 pp = pp < npix_total ? pp : npix_total - 1;
 #pragma unroll
                 for (int nt = 0; nt < NT; ++nt) {
-                    const int n = SPEC ? nt * 16 + 4 * g : min(nbase + nt * 16 + 4 * g, d.n_store - 4);
+                    const int n = SPEC ? (nt == NT - 1 && NT > 1 && !lastok ? (nt - 1) * 16 + 4 * g : nt * 16 + 4 * g)
+                                       : min(nbase + nt * 16 + 4 * g, d.n_store - 4);
                     if (has_r1) r1v[nt] = *reinterpret_cast<const f32x4*>(d.r1 + pp * d.ldr1 + n);
                     if (has_r2) r2v[nt] = Vec4<T>::load_raw(reinterpret_cast<const T*>(d.r2) + pp * d.ldr2 + n);
                 }
@@ -194,10 +200,18 @@ __global__ __launch_bounds__(WAVES * 64, MINW) void pw_kernel(const HatConvDesc 
                 const long ps = SPEC ? pc : p;
 #pragma unroll
                 for (int nt = 0; nt < NT; ++nt) {
-                    const int n = nbase + nt * 16 + 4 * g;
+                    int n = nbase + nt * 16 + 4 * g;
+                    f32x4 v = acc[nt];
+                    if constexpr (SPEC && NT > 1) {
+                        if (nt == NT - 1) {   // partial last tile: re-store the previous tile's value (selects, no branch)
+                            n = lastok ? n : n - 16;
+#pragma unroll
+                            for (int r = 0; r < 4; ++r) v[r] = lastok ? v[r] : acc[NT - 2][r];
+                        }
+                    }
                     if (SPEC || n < d.n_store) {
-                        if (!out_f32) Vec4<T>::store(reinterpret_cast<T*>(d.out) + ps * d.ldo + n, acc[nt]);
-                        else *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(d.out) + ps * d.ldo + n) = acc[nt];
+                        if (!out_f32) Vec4<T>::store(reinterpret_cast<T*>(d.out) + ps * d.ldo + n, v);
+                        else *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(d.out) + ps * d.ldo + n) = v;
                     }
                 }
             }
@@ -268,14 +282,15 @@ __global__ __launch_bounds__(WAVES * 64, MINW) void pw_kernel(const HatConvDesc 
     // specialised copies need: one slice that stores all NT*16 channels, no split source oddities beyond load_b's, and
     // (with r2) the scale table in LDS
     const bool full = d.n_slices == 1 && d.n_store == NT * 16;
+    const bool tail_ok = d.n_slices == 1 && NT > 1 && d.n_store > (NT - 1) * 16 && d.n_store <= NT * 16;  // partial last tile
     // T-typed rows leave the specialised copies in 16-byte pieces (store_pair_bf16)
     const bool out16 = d.ldo % 8 == 0 && reinterpret_cast<uintptr_t>(d.out) % 16 == 0;
     const bool ln16 = d.ld_ln % 8 == 0 && reinterpret_cast<uintptr_t>(d.ln_out) % 16 == 0;
     if constexpr (RES) {
         const bool f32o = d.out_mode == HAT_O_NHWC_F32;
-        if (full && f32o && d.r1 && d.r2 && scale_in_lds && !emit_ln) tile_loop(PwTag<true, true, true, true, false>{});
+        if (tail_ok && f32o && d.r1 && d.r2 && scale_in_lds && !emit_ln) tile_loop(PwTag<true, true, true, true, false>{});
         else if (full && f32o && d.r1 && !d.r2 && emit_ln && !d.ln_ones && ln16) tile_loop(PwTag<true, true, false, true, true>{});
-        else if (full && f32o && d.r1 && !d.r2 && !emit_ln) tile_loop(PwTag<true, true, false, true, false>{});
+        else if (tail_ok && f32o && d.r1 && !d.r2 && !emit_ln) tile_loop(PwTag<true, true, false, true, false>{});
         else tile_loop(PwTag<false, false, false, false, false>{});
     } else {
         if (full && d.out_mode == HAT_O_NHWC_T && out16) tile_loop(PwTag<true, false, false, false, false>{});
