@@ -31,7 +31,7 @@ __host__ inline size_t conv_lds_bytes(const HatConvDesc& d, int waves, int pt, i
 
 __host__ inline bool conv_pick(const HatConvDesc& d, TileCfg* out, size_t* lds) {
     const int es = d.dtype == HAT_BF16 ? 2 : 4;
-    const int kc = (d.dtype == HAT_BF16 ? 64 : 32) * (d.nt == 1 ? 3 : 1);
+    const int kc = (d.dtype == HAT_BF16 ? 64 : 32) * (d.nt == 1 ? 3 : (d.nt <= 4 ? 2 : 1));
     const TileCfg cands[3] = {{8, 2}, {4, 2}, {4, 1}};
     // first choice: the largest tile that still lets TWO workgroups share a CU (LDS <= 80 KiB each), so one
     // workgroup's load / store phases overlap the other's MFMA phase — only when the weight slice is cheap to
@@ -56,8 +56,9 @@ __global__ __launch_bounds__(WAVES * 64) void conv_kernel(const HatConvDesc d) {
     constexpr int NTHR = WAVES * 64;
     constexpr int TROWS = WAVES * PT;
     // one-n-tile layers (CAB conv 144->6, the 13x13 ESC conv, conv_last) do 1 MFMA per k-step per pixel tile: their
-    // chunk is 3x longer so the two barriers per chunk are amortised over 3x the work
-    constexpr int KC = M::KC * (NT == 1 ? 3 : 1);
+    // chunk is 3x longer so the two barriers per chunk are amortised over 3x the work; up to 4 n-tiles (CAB squeeze of
+    // the C = 180 models, conv_before_upsample) 2x.  Wider layers keep 64: the longer chunk's fetch registers spill there.
+    constexpr int KC = M::KC * (NT == 1 ? 3 : (NT <= 4 ? 2 : 1));
     constexpr int KS = KC / 32;
     constexpr int PPR = KC * (int)sizeof(T) / 16;  // 16-byte pieces per weight-chunk row
     constexpr int VEC = M::VEC;
@@ -372,7 +373,7 @@ int conv_validate(const HatConvDesc& d) {
     if (d.B < 1 || d.H < 1 || d.W < 1 || d.Cin < 1) return HAT_EINVAL;
     if (d.ksize < 1 || (d.ksize & 1) == 0 || d.ksize > 13) return HAT_EINVAL;
     if (d.dtype != HAT_F32 && d.dtype != HAT_BF16) return HAT_EINVAL;
-    const int kc = (d.dtype == HAT_BF16 ? 64 : 32) * (d.nt == 1 ? 3 : 1), vec = d.dtype == HAT_BF16 ? 8 : 4;
+    const int kc = (d.dtype == HAT_BF16 ? 64 : 32) * (d.nt == 1 ? 3 : (d.nt <= 4 ? 2 : 1)), vec = d.dtype == HAT_BF16 ? 8 : 4;
     const int cin_p = (d.Cin + 7) & ~7;
     if (d.Kpad % kc || d.Kpad < d.ksize * d.ksize * cin_p) return HAT_EINVAL;
     if (d.n_slices < 1 || d.n_store < 1 || d.n_store > d.n_slices * d.nt * 16) return HAT_EINVAL;

@@ -110,7 +110,7 @@ def pack_conv_weight(weight: torch.Tensor, bias: Optional[torch.Tensor], dtype: 
         nt, n_slices = choose_nt(o)
     else:
         n_slices = -(-o // (16 * nt))
-    kc = KC[dtype] * (3 if nt == 1 else 1)  # one-n-tile layers use a 3x longer weight chunk (hat_conv.hip)
+    kc = KC[dtype] * (3 if nt == 1 else (2 if nt <= 4 else 1))  # weight chunk length of hat_conv.hip: longer for few n-tiles
     kpad = -(-k // kc) * kc
     npad = nt * 16 * n_slices
     wp = torch.zeros(npad, kpad, dtype=torch.float32)
