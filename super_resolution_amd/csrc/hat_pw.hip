@@ -16,8 +16,9 @@
 
 namespace {
 
-template <bool SPEC_, bool R1_, bool R2_, bool OUTF32_, bool LN_> struct PwTag {
-    static constexpr bool spec = SPEC_, r1 = R1_, r2 = R2_, outf32 = OUTF32_, ln = LN_;
+template <bool SPEC_, bool R1_, bool R2_, bool OUTF32_, bool LN_, bool PAIR_ = false> struct PwTag {
+    // pair: bf16 rows (out / ln_out) leave as 16-byte stores of n-tile pairs — needs every n-tile full and aligned rows
+    static constexpr bool spec = SPEC_, r1 = R1_, r2 = R2_, outf32 = OUTF32_, ln = LN_, pair = PAIR_;
 };
 
 // RES: the launch has residual operands (r1 and/or r2): their loads are batched ahead of the MFMAs (+54 registers)
@@ -190,7 +191,7 @@ __global__ __launch_bounds__(WAVES * 64, MINW) void pw_kernel(const HatConvDesc 
                 bcur[ks] = bnxt[ks];
                 if constexpr (DEEP) bnxt[ks] = bnx2[ks];
             }
-            if constexpr (SPEC && !Tag::outf32 && sizeof(T) == 2) {
+            if constexpr (SPEC && !Tag::outf32 && sizeof(T) == 2 && Tag::pair) {
                 // full tiles, bf16 rows: n-tiles leave in pairs, 16 bytes per lane (store_pair_bf16)
                 bf16_t* orow = reinterpret_cast<bf16_t*>(d.out) + pc * d.ldo;
 #pragma unroll
@@ -222,6 +223,12 @@ __global__ __launch_bounds__(WAVES * 64, MINW) void pw_kernel(const HatConvDesc 
 #pragma unroll
                     for (int nt = 0; nt < NT; ++nt) {
                         if (!SPEC && nt * 16 + 4 * g >= C) acc[nt] = f32x4{0.f, 0.f, 0.f, 0.f};
+                        if constexpr (SPEC && NT > 1) {   // partial last tile: zero by select
+                            if (nt == NT - 1) {
+#pragma unroll
+                                for (int r = 0; r < 4; ++r) acc[nt][r] = lastok ? acc[nt][r] : 0.f;
+                            }
+                        }
                         sm += (acc[nt][0] + acc[nt][1]) + (acc[nt][2] + acc[nt][3]);
                     }
                     sm += __shfl_xor(sm, 16); sm += __shfl_xor(sm, 32);
@@ -231,7 +238,11 @@ __global__ __launch_bounds__(WAVES * 64, MINW) void pw_kernel(const HatConvDesc 
                     for (int nt = 0; nt < NT; ++nt) {
                         if (SPEC || nt * 16 + 4 * g < C) {
 #pragma unroll
-                            for (int r = 0; r < 4; ++r) { const float dl = acc[nt][r] - mean; qq += dl * dl; }
+                            for (int r = 0; r < 4; ++r) {
+                                float dl = acc[nt][r] - mean;
+                                if (SPEC && NT > 1 && nt == NT - 1) dl = lastok ? dl : 0.f;
+                                qq += dl * dl;
+                            }
                         }
                     }
                     qq += __shfl_xor(qq, 16); qq += __shfl_xor(qq, 32);
@@ -245,7 +256,7 @@ __global__ __launch_bounds__(WAVES * 64, MINW) void pw_kernel(const HatConvDesc 
                         for (int r = 0; r < 4; ++r) o[r] = (acc[nt][r] - mean) * rstd * gm[r] + bt[r];
                         return o;
                     };
-                    if constexpr (SPEC && sizeof(T) == 2) {   // full tiles: 16-byte stores of n-tile pairs
+                    if constexpr (SPEC && sizeof(T) == 2 && Tag::pair) {   // full tiles: 16-byte stores of n-tile pairs
                         bf16_t* lo = reinterpret_cast<bf16_t*>(d.ln_out) + pc * d.ld_ln;
 #pragma unroll
                         for (int nt = 0; nt + 1 < NT; nt += 2) store_pair_bf16(lo, nt * 16, g, ln_val(nt), ln_val(nt + 1));
@@ -254,13 +265,17 @@ __global__ __launch_bounds__(WAVES * 64, MINW) void pw_kernel(const HatConvDesc 
                         T* lo = reinterpret_cast<T*>(d.ln_out) + (SPEC ? pc : p) * d.ld_ln;
 #pragma unroll
                         for (int nt = 0; nt < NT; ++nt) {
-                            const int n = nt * 16 + 4 * g;
+                            int n = nt * 16 + 4 * g;
                             if (SPEC || n < C) {
-                                const f32x4 gm = *reinterpret_cast<const f32x4*>(lnp + n);
-                                const f32x4 bt = *reinterpret_cast<const f32x4*>(lnp + NT * 16 + n);
-                                f32x4 o;
+                                f32x4 o = ln_val(nt);
+                                if constexpr (SPEC && NT > 1) {
+                                    if (nt == NT - 1) {   // partial last tile: re-store the previous tile's value
+                                        const f32x4 op = ln_val(NT - 2);
+                                        n = lastok ? n : n - 16;
 #pragma unroll
-                                for (int r = 0; r < 4; ++r) o[r] = (acc[nt][r] - mean) * rstd * gm[r] + bt[r];
+                                        for (int r = 0; r < 4; ++r) o[r] = lastok ? o[r] : op[r];
+                                    }
+                                }
                                 Vec4<T>::store(lo + n, o);
                             }
                         }
@@ -289,11 +304,13 @@ __global__ __launch_bounds__(WAVES * 64, MINW) void pw_kernel(const HatConvDesc 
     if constexpr (RES) {
         const bool f32o = d.out_mode == HAT_O_NHWC_F32;
         if (tail_ok && f32o && d.r1 && d.r2 && scale_in_lds && !emit_ln) tile_loop(PwTag<true, true, true, true, false>{});
-        else if (full && f32o && d.r1 && !d.r2 && emit_ln && !d.ln_ones && ln16) tile_loop(PwTag<true, true, false, true, true>{});
+        else if (full && f32o && d.r1 && !d.r2 && emit_ln && !d.ln_ones && ln16) tile_loop(PwTag<true, true, false, true, true, true>{});
+        else if (tail_ok && f32o && d.r1 && !d.r2 && emit_ln && !d.ln_ones) tile_loop(PwTag<true, true, false, true, true, false>{});
         else if (tail_ok && f32o && d.r1 && !d.r2 && !emit_ln) tile_loop(PwTag<true, true, false, true, false>{});
         else tile_loop(PwTag<false, false, false, false, false>{});
     } else {
-        if (full && d.out_mode == HAT_O_NHWC_T && out16) tile_loop(PwTag<true, false, false, false, false>{});
+        if (full && d.out_mode == HAT_O_NHWC_T && out16) tile_loop(PwTag<true, false, false, false, false, true>{});
+        else if (tail_ok && d.out_mode == HAT_O_NHWC_T) tile_loop(PwTag<true, false, false, false, false, false>{});
         else tile_loop(PwTag<false, false, false, false, false>{});
     }
 }
