@@ -199,6 +199,24 @@ int hat_ocab_attention(const void* q, const void* kv, const float* bias_rot, voi
                        int32_t ldkv, int32_t ldo, int32_t dtype, void* stream);
 
 /*
+ * CAB squeeze conv: GELU_erf(conv3x3(x, C -> mid <= 8 channels, zero pad) + bias)   (hat_arch.py:84-85, cab.0 + GELU)
+ * for bf16 rows without LDS operand traffic: a wave sweeps a 16-pixel-wide strip of rows, activations come straight from
+ * global memory, the weights stay in registers, and the three taps of a kernel column are routed to three rolling
+ * output-row accumulators by the choice of MFMA C operand (csrc/hat_cabsq.hip).
+ * x: (B,H,W,ldx) bf16, 128 < C <= 160, C % 8 == 0; W % 16 == 0.
+ * wpk: 6 tiles x 5 k-steps of MFMA A fragments [tile][kstep][64 lanes][8] bf16, tile = 2*kx + j:
+ *      j = 0: rows 0-7 = w[ch][.][ky=0][kx], rows 8-15 = w[ch][.][ky=1][kx];  j = 1: rows 0-7 = w[ch][.][ky=2][kx], rest 0
+ *      (fragment element [lane][e] = row lane%16, input channel 32*kstep + 8*(lane/16) + e; channels >= C are zero).
+ * bias: 8 floats (zeros past mid).  out: (B,H,W,8) bf16, channels >= mid are exact zeros.
+ * colsum (optional): [B][units][16] fp32 per-wave-unit channel sums of the stored values (what hat_cab_fold consumes as
+ * c1_colsum with tiles = units, ldcs = 16); units from hat_cab_squeeze_units.  dtype must be HAT_BF16 (the fp32 parity
+ * path uses hat_conv).
+ */
+int hat_cab_squeeze_units(int32_t H, int32_t W, int32_t* rows_per_band, int32_t* units);
+int hat_cab_squeeze(const void* x, const void* wpk, const float* bias, void* out, float* colsum, int32_t B, int32_t H,
+                    int32_t W, int32_t C, int32_t ldx, int32_t dtype, void* stream);
+
+/*
  * (Shifted-)window self-attention, (S)W-MSA — SURVEY §8 row f2.  Replaces, for one attention branch of a Swin / upstream-HAT
  * block, ESC/basicsr/archs/swinir_arch.py:291-317 (torch.roll by -shift, window_partition, WindowAttention core :147-168
  * with the relative-position bias :153-156 and the shift mask of calculate_mask :262-280, window_reverse, torch.roll by

@@ -142,6 +142,9 @@ class HATEngine:
                         and not os.environ.get("HAT_NO_CAB_FOLD")):
                     hb["fold"] = {"w2": w2raw.detach().to(**f32).contiguous(), "b2": vec(p + ".conv_block.cab.2.bias"),
                                   "ba": vec(hb["esc"].aggr_keys[1])}
+                    # squeeze conv on the row-sweep kernel (no LDS operand traffic) where it is instantiated
+                    if ops.cab_squeeze_supported(C, w2raw.shape[1], 16, dt) and not os.environ.get("HAT_NO_CAB_SWEEP"):
+                        hb["fold"]["sq"] = ops.pack_cab_squeeze(sd[p + ".conv_block.cab.0.weight"], sd[p + ".conv_block.cab.0.bias"], dev)
                 if not self.fuse_ffn:
                     hb["fc1"] = self._lin(sd, p + ".mlp.fc1.weight", p + ".mlp.fc1.bias")
                     hb["fc2"] = self._lin(sd, p + ".mlp.fc2.weight", p + ".mlp.fc2.bias")
@@ -232,7 +235,8 @@ class HATEngine:
         hab0 = self.layers[0]["habs"][0] if self.layers and self.layers[0]["habs"] else None
         if hab0 is not None and "fold" in hab0:
             cab0 = hab0["cab0"]
-            w["tiles1"] = ops.conv_tiles(cab0, H, W, self.dtype)
+            w["sweep"] = "sq" in hab0["fold"] and W % 16 == 0 and cab0.npad == 16
+            w["tiles1"] = ops.cab_squeeze_units(H, W) if w["sweep"] else ops.conv_tiles(cab0, H, W, self.dtype)
             w["colsum1"] = z(B, w["tiles1"], cab0.npad, dtype=f)
             w["wf"] = z(B, hab0["esc"].aggr.nt * 3 * 512)
             w["bias_b"] = z(B, hab0["esc"].aggr.npad, dtype=f)
@@ -319,7 +323,10 @@ class HATEngine:
                         self._esc_w(esc, w, B, H, W, nblk)
                         self._esc_conv(esc, w, w["n"], B, H, W)
                     # chain 1: CAB squeeze conv -> fold
-                    ops.conv(hb["cab0"], w["n"], w["c1"], **geo, ldx=ldc, ldo=8, act=ACT_GELU, n_store=8, colsum=w["colsum1"])
+                    if w["sweep"]:
+                        ops.cab_squeeze(w["n"], fo["sq"][0], fo["sq"][1], w["c1"], w["colsum1"], B=B, H=H, W=W, C_=C, ldx=ldc, dtype=dt)
+                    else:
+                        ops.conv(hb["cab0"], w["n"], w["c1"], **geo, ldx=ldc, ldo=8, act=ACT_GELU, n_store=8, colsum=w["colsum1"])
                     ops.cab_fold(w["c1"], w["colsum1"], w["tiles1"], hb["cab0"].npad, fo["w2"], fo["b2"], hb["eca_w"],
                                  hb["eca_w"].numel(), fo["ba"], float(cfg["conv_scale"]), w["scale"], w["wf"], w["bias_b"],
                                  w["eca_tmp"], B=B, H=H, W=W, C_=C, mid=mid, dtype=dt)

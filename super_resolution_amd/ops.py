@@ -207,6 +207,46 @@ def ocab_attention(q, kv, bias_rot, out, *, B: int, H: int, W: int, C_: int, hea
                                _stream()), "hat_ocab_attention"))
 
 
+# ------------------------------------------------------------------------------------------------
+# CAB squeeze conv on the row-sweep kernel (hat_cab_squeeze)
+# ------------------------------------------------------------------------------------------------
+def cab_squeeze_supported(C_: int, mid: int, W: int, dtype: int) -> bool:
+    return dtype == HAT_BF16 and 128 < C_ <= 160 and C_ % 8 == 0 and mid <= 8 and W % 16 == 0
+
+
+def pack_cab_squeeze(weight: torch.Tensor, bias: torch.Tensor, device):
+    """cab.0 weight (mid, C, 3, 3) -> the 6 x 5 MFMA A fragments hat_cab_squeeze keeps in registers, + 8 bias floats."""
+    w = weight.detach().to(torch.float32).cpu()
+    mid, cin = w.shape[0], w.shape[1]
+    A = torch.zeros(6, 16, 160)                      # [tile][row][k]
+    for kx in range(3):
+        A[2 * kx, 0:mid, :cin] = w[:, :, 0, kx]      # ky = 0 -> output row r + 1
+        A[2 * kx, 8:8 + mid, :cin] = w[:, :, 1, kx]  # ky = 1 -> output row r
+        A[2 * kx + 1, 0:mid, :cin] = w[:, :, 2, kx]  # ky = 2 -> output row r - 1
+    lane = torch.arange(64)
+    row = (lane & 15)[None, None, :, None].expand(6, 5, 64, 8)
+    col = (torch.arange(5)[None, :, None, None] * 32 + 8 * (lane >> 4)[None, None, :, None] + torch.arange(8)[None, None, None, :]).expand(6, 5, 64, 8)
+    tile = torch.arange(6)[:, None, None, None].expand(6, 5, 64, 8)
+    wpk = A[tile, row, col].to(torch.bfloat16).contiguous().to(device)
+    b8 = torch.zeros(8)
+    b8[:mid] = bias.detach().to(torch.float32).cpu()
+    return wpk, b8.to(device)
+
+
+def cab_squeeze_units(H: int, W: int) -> int:
+    lib = _lib.load()
+    rows, units = C.c_int32(0), C.c_int32(0)
+    _lib.check(lib.hat_cab_squeeze_units(H, W, C.byref(rows), C.byref(units)), "hat_cab_squeeze_units")
+    return units.value
+
+
+def cab_squeeze(x, wpk, bias8, out, colsum, *, B: int, H: int, W: int, C_: int, ldx: int, dtype: int):
+    lib = _lib.load()
+    _timed("cab_squeeze_kernel", 2.0 * B * H * W * 9 * C_ * 6, lambda: _lib.check(
+        lib.hat_cab_squeeze(_ptr(x), _ptr(wpk), _ptr(bias8), _ptr(out), _ptr(colsum), B, H, W, C_, ldx, dtype, _stream()),
+        "hat_cab_squeeze"), tag=f"k3 {C_}->8 {H}x{W} row sweep")
+
+
 def window_attention(q, kv, bias_flip, out, *, B: int, H: int, W: int, C_: int, heads: int, ws: int, shift: int, ldq: int,
                      ldkv: int, ldo: int, dtype: int):
     """(S)W-MSA core (hat_window_attention; swinir_arch.py:147-168 + roll / partition / mask / reverse :291-317)."""

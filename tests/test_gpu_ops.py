@@ -611,3 +611,36 @@ def test_window_attention_rejects_bad_arguments():
     for bad in (dict(shift=3), dict(shift=16), dict(H=24), dict(ws=12)):
         with pytest.raises(RuntimeError):
             ops.window_attention(t, t.view(-1)[48:], bias, o, **{**kw, "shift": 0, **bad})
+
+
+# ------------------------------------------------------------------------------------------------
+# CAB squeeze conv on the row-sweep kernel (hat_cab_squeeze)
+# ------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("geom", [(1, 48, 64, 144, 6), (2, 21, 32, 144, 6), (1, 8, 16, 136, 8), (1, 100, 48, 160, 3)],
+                         ids=["48x64", "B2_21x32_ragged_rows", "one_band_C136_mid8", "C160_mid3"])
+def test_cab_squeeze_row_sweep(geom):
+    """GELU(conv3x3(x) + b) with <= 8 output channels against F.conv2d in fp64 on the bf16-rounded operands, including the
+    per-unit channel sums (their total must equal the sum of the stored fp32 values within bf16 rounding of the outputs)."""
+    dev = _dev()
+    ops = _ops()
+    from super_resolution_amd._lib import HAT_BF16
+    B, H, W, C, mid = geom
+    x = rnd(f"cabsq.x{geom}", (B, H, W, C)).to(torch.bfloat16)
+    w = rnd(f"cabsq.w{geom}", (mid, C, 3, 3), std=(9 * C) ** -0.5)
+    b = rnd(f"cabsq.b{geom}", (mid,), std=0.1)
+    assert ops.cab_squeeze_supported(C, mid, W, HAT_BF16)
+    wpk, b8 = ops.pack_cab_squeeze(w, b, dev)
+    units = ops.cab_squeeze_units(H, W)
+    xd = x.to(dev).contiguous()
+    out = torch.full((B, H, W, 8), 7.0, dtype=torch.bfloat16, device=dev)
+    cs = torch.full((B, units, 16), 7.0, dtype=torch.float32, device=dev)
+    ops.cab_squeeze(xd, wpk, b8, out, cs, B=B, H=H, W=W, C_=C, ldx=C, dtype=HAT_BF16)
+    torch.cuda.synchronize()
+    ref = F.gelu(F.conv2d(x.double().permute(0, 3, 1, 2), w.to(torch.bfloat16).double(), b.double(), padding=1)).permute(0, 2, 3, 1)
+    got = out.float().cpu()
+    check(got[..., :mid], ref.float(), "bf16", f"cab squeeze {geom}")
+    if mid < 8:
+        assert float(got[..., mid:].abs().max()) == 0.0
+    tot = cs.sum(1).cpu()
+    assert float(tot[:, 8:].abs().max()) == 0.0
+    assert torch.allclose(tot[:, :mid].double(), ref.sum((1, 2)), rtol=2e-3, atol=2e-2 * (H * W) ** 0.5)
