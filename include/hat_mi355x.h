@@ -217,6 +217,16 @@ int hat_cab_squeeze(const void* x, const void* wpk, const float* bias, void* out
                     int32_t W, int32_t C, int32_t ldx, int32_t dtype, void* stream);
 
 /*
+ * conv_last (hat_arch.py:757, 856-858): out = (conv3x3(x, 64 -> n_out <= 8) + bias) * out_scale + mean[ch], written as
+ * (B, n_out, H, W) fp32 planes — the same row-sweep kernel as hat_cab_squeeze with two k-steps (num_feat = 64,
+ * hat_arch.py:656).  x: (B,H,W,ldx) bf16; wpk: 6 tiles x 2 k-steps of A fragments in hat_cab_squeeze's tile order;
+ * bias: 8 floats; mean4: 4 floats (the RGB mean, or zeros); W % 16 == 0; dtype must be HAT_BF16.
+ */
+int hat_conv3x3_to_planes(const void* x, const void* wpk, const float* bias, float* out, int32_t B, int32_t H, int32_t W,
+                          int32_t C, int32_t ldx, int32_t n_out, float out_scale, const float* mean4, int32_t dtype,
+                          void* stream);
+
+/*
  * (Shifted-)window self-attention, (S)W-MSA — SURVEY §8 row f2.  Replaces, for one attention branch of a Swin / upstream-HAT
  * block, ESC/basicsr/archs/swinir_arch.py:291-317 (torch.roll by -shift, window_partition, WindowAttention core :147-168
  * with the relative-position bias :153-156 and the shift mask of calculate_mask :262-280, window_reverse, torch.roll by

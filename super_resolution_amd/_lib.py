@@ -103,6 +103,8 @@ SIGNATURES = {
     "hat_cab_squeeze_units": (C.c_int, [C.c_int32, C.c_int32, C.c_void_p, C.c_void_p]),
     "hat_cab_squeeze": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32,
                                   C.c_int32, C.c_int32, C.c_int32, C.c_void_p]),
+    "hat_conv3x3_to_planes": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32,
+                                        C.c_int32, C.c_int32, C.c_float, C.c_void_p, C.c_int32, C.c_void_p]),
     "hat_window_attention": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32,
                                        C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32,
                                        C.c_int32, C.c_void_p]),

@@ -16,15 +16,17 @@
 
 namespace {
 
-constexpr int CABSQ_KS = 5;   // k-steps: C = 144 padded to 160
+// KS = k-steps (C padded to 32 KS).  NCHW = false: bias + GELU -> (B,H,W,8) bf16 + per-unit channel sums (CAB squeeze);
+// NCHW = true: (acc + bias) * out_scale + mean[ch] -> (B,nst,H,W) fp32 planes (conv_last, hat_arch.py:856-858).
+struct SweepEpi { float out_scale; float mean[4]; int nst; };
 
-__global__ __launch_bounds__(256, 2) void cab_squeeze_kernel(const bf16_t* __restrict__ x, const bf16_t* __restrict__ wpk,
-                                                             const float* __restrict__ bias, bf16_t* __restrict__ out,
+template <int KS, bool NCHW>
+__global__ __launch_bounds__(256, KS > 2 ? 2 : 3) void cab_squeeze_kernel(const bf16_t* __restrict__ x, const bf16_t* __restrict__ wpk,
+                                                             const float* __restrict__ bias, void* __restrict__ outv,
                                                              float* __restrict__ colsum, int H, int W, int C, int ldx,
-                                                             int rows, int strips, int units) {
+                                                             int rows, int strips, int units, SweepEpi epi) {
     using M = MT<bf16_t>;
     using frag_t = M::frag_t;
-    constexpr int KS = CABSQ_KS;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, g = lane >> 4, c16 = lane & 15;
     const int u = blockIdx.x * 4 + wave;          // wave unit: (band, strip), strips of one band adjacent
     const int b = blockIdx.y;
@@ -32,7 +34,8 @@ __global__ __launch_bounds__(256, 2) void cab_squeeze_kernel(const bf16_t* __res
     const int band = u / strips, strip = u - band * strips;
     const int x0 = strip * 16, y0 = band * rows, y1 = min(y0 + rows, H);
     const bf16_t* xb = x + (size_t)b * H * W * ldx;
-    bf16_t* ob = out + (size_t)b * H * W * 8;
+    bf16_t* ob = reinterpret_cast<bf16_t*>(outv) + (size_t)b * H * W * 8;
+    float* of = reinterpret_cast<float*>(outv) + (size_t)b * epi.nst * H * W;
 
     frag_t A[6][KS];   // [2 * kx + (0: T1, 1: T2)][k-step], fragment-packed on the host: one coalesced 1 KB load each
 #pragma unroll
@@ -87,10 +90,16 @@ __global__ __launch_bounds__(256, 2) void cab_squeeze_kernel(const bf16_t* __res
         for (int i = 0; i < 4; ++i) v[i] = S2[i] + __shfl_xor(S0[i], 32);
         if (y >= y0 && y < y1 && g < 2) {
             v += bs;
+            if constexpr (NCHW) {
 #pragma unroll
-            for (int i = 0; i < 4; ++i) v[i] = gelu_erf_fast(v[i]);
-            Vec4<bf16_t>::store(ob + ((size_t)y * W + x0 + c16) * 8 + 4 * g, v);
-            csum += v;
+                for (int i = 0; i < 4; ++i)
+                    if (4 * g + i < epi.nst) of[((size_t)(4 * g + i) * H + y) * W + x0 + c16] = v[i] * epi.out_scale + epi.mean[(4 * g + i) & 3];
+            } else {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) v[i] = gelu_erf_fast(v[i]);
+                Vec4<bf16_t>::store(ob + ((size_t)y * W + x0 + c16) * 8 + 4 * g, v);
+                csum += v;
+            }
         }
         S2 = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
@@ -106,7 +115,7 @@ __global__ __launch_bounds__(256, 2) void cab_squeeze_kernel(const bf16_t* __res
         if (r + 1 <= y1) step(r + 1, ring[2], ring[0], ring[1]);
         if (r + 2 <= y1) step(r + 2, ring[0], ring[1], ring[2]);
     }
-    if (colsum != nullptr) {   // per-unit channel sums of the stored values (hat_cab_fold's ECA pooling)
+    if (!NCHW && colsum != nullptr) {   // per-unit channel sums of the stored values (hat_cab_fold's ECA pooling)
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const float s = row_sum16(csum[i]);
@@ -117,11 +126,10 @@ __global__ __launch_bounds__(256, 2) void cab_squeeze_kernel(const bf16_t* __res
 
 }  // namespace
 
-extern "C" int hat_cab_squeeze_units(int32_t H, int32_t W, int32_t* rows_out, int32_t* units_out) {
-    if (H < 1 || W < 16 || W % 16 || !rows_out || !units_out) return HAT_EINVAL;
+static int sweep_units(int H, int W, int slots, int* rows_out, int* units_out) {
     const int strips = W / 16;
-    // one round of wave units on 256 CUs x 8 waves when the frame allows it; never fewer than 8 rows per band (2 halo rows each)
-    int bands = 2048 / strips;
+    // one round of wave units on the chip's wave slots when the frame allows it; never fewer than 8 rows per band (2 halo rows each)
+    int bands = slots / strips;
     bands = bands < 1 ? 1 : bands;
     int rows = (H + bands - 1) / bands;
     rows = rows < 8 ? 8 : rows;
@@ -130,17 +138,37 @@ extern "C" int hat_cab_squeeze_units(int32_t H, int32_t W, int32_t* rows_out, in
     return 0;
 }
 
+extern "C" int hat_cab_squeeze_units(int32_t H, int32_t W, int32_t* rows_out, int32_t* units_out) {
+    if (H < 1 || W < 16 || W % 16 || !rows_out || !units_out) return HAT_EINVAL;
+    return sweep_units(H, W, 2048, rows_out, units_out);   // 256 CUs x 4 SIMDs x 2 waves (248 registers)
+}
+
 extern "C" int hat_cab_squeeze(const void* x, const void* wpk, const float* bias, void* out, float* colsum, int32_t B,
                                int32_t H, int32_t W, int32_t C, int32_t ldx, int32_t dtype, void* stream) {
     if (!x || !wpk || !bias || !out || B < 1 || H < 1) return HAT_EINVAL;
     if (dtype != HAT_BF16) return HAT_EUNSUPPORTED;   // the fp32 parity path uses hat_conv
-    if (C % 8 || C < 8 || C > 32 * CABSQ_KS || C <= 32 * (CABSQ_KS - 1) || ldx < C || ldx % 8) return HAT_EUNSUPPORTED;
+    if (C % 8 || C > 160 || C <= 128 || ldx < C || ldx % 8) return HAT_EUNSUPPORTED;
     if ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(wpk)) % 16 || reinterpret_cast<uintptr_t>(out) % 8) return HAT_EINVAL;
     int32_t rows = 0, units = 0;
     const int rc = hat_cab_squeeze_units(H, W, &rows, &units);
     if (rc) return rc;
-    HAT_LAUNCH(cab_squeeze_kernel, dim3((units + 3) / 4, B), dim3(256), 0, reinterpret_cast<hipStream_t>(stream),
-               reinterpret_cast<const bf16_t*>(x), reinterpret_cast<const bf16_t*>(wpk), bias, reinterpret_cast<bf16_t*>(out),
-               colsum, H, W, C, ldx, rows, W / 16, units);
+    HAT_LAUNCH((cab_squeeze_kernel<5, false>), dim3((units + 3) / 4, B), dim3(256), 0, reinterpret_cast<hipStream_t>(stream),
+               reinterpret_cast<const bf16_t*>(x), reinterpret_cast<const bf16_t*>(wpk), bias, out, colsum, H, W, C, ldx, rows,
+               W / 16, units, SweepEpi{1.0f, {0.f, 0.f, 0.f, 0.f}, 8});
+    return hat_check_launch();
+}
+
+extern "C" int hat_conv3x3_to_planes(const void* x, const void* wpk, const float* bias, float* out, int32_t B, int32_t H,
+                                     int32_t W, int32_t C, int32_t ldx, int32_t n_out, float out_scale, const float* mean4,
+                                     int32_t dtype, void* stream) {
+    if (!x || !wpk || !bias || !out || !mean4 || B < 1 || H < 1 || W < 16 || W % 16 || n_out < 1 || n_out > 8) return HAT_EINVAL;
+    if (dtype != HAT_BF16) return HAT_EUNSUPPORTED;
+    if (C != 64 || ldx < C || ldx % 8) return HAT_EUNSUPPORTED;   // conv_last: num_feat = 64 (hat_arch.py:656)
+    if ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(wpk)) % 16) return HAT_EINVAL;
+    int rows = 0, units = 0;
+    sweep_units(H, W, 3072, &rows, &units);                 // 3 waves per SIMD at 2 k-steps
+    HAT_LAUNCH((cab_squeeze_kernel<2, true>), dim3((units + 3) / 4, B), dim3(256), 0, reinterpret_cast<hipStream_t>(stream),
+               reinterpret_cast<const bf16_t*>(x), reinterpret_cast<const bf16_t*>(wpk), bias, out, nullptr, H, W, C, ldx, rows,
+               W / 16, units, SweepEpi{out_scale, {mean4[0], mean4[1], mean4[2], mean4[3]}, n_out});
     return hat_check_launch();
 }

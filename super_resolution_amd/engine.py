@@ -189,6 +189,10 @@ class HATEngine:
         else:
             raise ValueError(f"scale {s} is not supported. Supported scales: 2^n and 3.")
         self.conv_last = P("conv_last.weight", "conv_last.bias")
+        wl = sd["conv_last.weight"]
+        self.conv_last_sweep = None   # row-sweep kernel (no LDS) for the 64 -> 3 conv at output resolution
+        if ops.conv3x3_to_planes_supported(wl.shape[0], wl.shape[1], 16, dt) and not os.environ.get("HAT_NO_CAB_SWEEP"):
+            self.conv_last_sweep = ops.pack_cab_squeeze(wl, sd["conv_last.bias"], dev) + (wl.shape[0],)
 
     def _pack_ps(self, sd, key, r):
         """Conv feeding nn.PixelShuffle(r) (hat_arch.py:598-602): output channel c*r^2 + i*r + j is stored
@@ -405,6 +409,10 @@ class HATEngine:
             ops.conv(pw, src, dst, B=B, H=h, W=wd, dtype=dt, ldx=64, ldo=64, out_mode=O_PIXSHUF_T, ps_r=rr)
             src, h, wd = dst, h * rr, wd * rr
         # conv_last ; / img_range + mean                                                   :856-858
-        ops.conv(self.conv_last, src, y, B=B, H=h, W=wd, dtype=dt, ldx=64, ldo=0, out_mode=O_NCHW_F32,
-                 out_scale=1.0 / r, mean=mean)
+        if self.conv_last_sweep is not None and wd % 16 == 0:
+            wpk, b8, nout = self.conv_last_sweep
+            ops.conv3x3_to_planes(src, wpk, b8, y, B=B, H=h, W=wd, C_=64, ldx=64, n_out=nout, out_scale=1.0 / r, mean=mean, dtype=dt)
+        else:
+            ops.conv(self.conv_last, src, y, B=B, H=h, W=wd, dtype=dt, ldx=64, ldo=0, out_mode=O_NCHW_F32,
+                     out_scale=1.0 / r, mean=mean)
         return y

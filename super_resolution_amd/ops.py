@@ -215,22 +215,39 @@ def cab_squeeze_supported(C_: int, mid: int, W: int, dtype: int) -> bool:
 
 
 def pack_cab_squeeze(weight: torch.Tensor, bias: torch.Tensor, device):
-    """cab.0 weight (mid, C, 3, 3) -> the 6 x 5 MFMA A fragments hat_cab_squeeze keeps in registers, + 8 bias floats."""
+    """3x3 weight (mid <= 8, C, 3, 3) -> the 6 x ceil(C/32) MFMA A fragments the row-sweep kernel keeps in registers
+    (hat_cab_squeeze / hat_conv3x3_to_planes), + 8 bias floats."""
     w = weight.detach().to(torch.float32).cpu()
     mid, cin = w.shape[0], w.shape[1]
-    A = torch.zeros(6, 16, 160)                      # [tile][row][k]
+    ks = -(-cin // 32)
+    A = torch.zeros(6, 16, 32 * ks)                  # [tile][row][k]
     for kx in range(3):
         A[2 * kx, 0:mid, :cin] = w[:, :, 0, kx]      # ky = 0 -> output row r + 1
         A[2 * kx, 8:8 + mid, :cin] = w[:, :, 1, kx]  # ky = 1 -> output row r
         A[2 * kx + 1, 0:mid, :cin] = w[:, :, 2, kx]  # ky = 2 -> output row r - 1
     lane = torch.arange(64)
-    row = (lane & 15)[None, None, :, None].expand(6, 5, 64, 8)
-    col = (torch.arange(5)[None, :, None, None] * 32 + 8 * (lane >> 4)[None, None, :, None] + torch.arange(8)[None, None, None, :]).expand(6, 5, 64, 8)
-    tile = torch.arange(6)[:, None, None, None].expand(6, 5, 64, 8)
+    shape = (6, ks, 64, 8)
+    row = (lane & 15)[None, None, :, None].expand(shape)
+    col = (torch.arange(ks)[None, :, None, None] * 32 + 8 * (lane >> 4)[None, None, :, None] + torch.arange(8)[None, None, None, :]).expand(shape)
+    tile = torch.arange(6)[:, None, None, None].expand(shape)
     wpk = A[tile, row, col].to(torch.bfloat16).contiguous().to(device)
     b8 = torch.zeros(8)
     b8[:mid] = bias.detach().to(torch.float32).cpu()
     return wpk, b8.to(device)
+
+
+def conv3x3_to_planes_supported(nout: int, cin: int, W: int, dtype: int) -> bool:
+    return dtype == HAT_BF16 and cin == 64 and nout <= 8 and W % 16 == 0
+
+
+def conv3x3_to_planes(x, wpk, bias8, out, *, B: int, H: int, W: int, C_: int, ldx: int, n_out: int, out_scale: float, mean,
+                      dtype: int):
+    """conv_last on the row-sweep kernel: (conv3x3 + bias) * out_scale + mean -> (B, n_out, H, W) fp32."""
+    lib = _lib.load()
+    m4 = (C.c_float * 4)(*[float(mean[i]) if i < len(mean) else 0.0 for i in range(4)])
+    _timed("cab_squeeze_kernel<2, planes>", 2.0 * B * H * W * 9 * C_ * n_out, lambda: _lib.check(
+        lib.hat_conv3x3_to_planes(_ptr(x), _ptr(wpk), _ptr(bias8), _ptr(out), B, H, W, C_, ldx, n_out, out_scale, m4, dtype,
+                                  _stream()), "hat_conv3x3_to_planes"), tag=f"k3 {C_}->{n_out} {H}x{W} row sweep planes")
 
 
 def cab_squeeze_units(H: int, W: int) -> int:

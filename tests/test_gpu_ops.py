@@ -644,3 +644,25 @@ def test_cab_squeeze_row_sweep(geom):
     tot = cs.sum(1).cpu()
     assert float(tot[:, 8:].abs().max()) == 0.0
     assert torch.allclose(tot[:, :mid].double(), ref.sum((1, 2)), rtol=2e-3, atol=2e-2 * (H * W) ** 0.5)
+
+
+@pytest.mark.parametrize("geom", [(1, 40, 64, 3), (2, 19, 32, 3), (1, 64, 48, 1)], ids=["40x64", "B2_19x32", "one_channel"])
+def test_conv_last_row_sweep_planes(geom):
+    """(conv3x3(x, 64 -> n) + b) * out_scale + mean as (B, n, H, W) fp32 planes against F.conv2d in fp64."""
+    dev = _dev()
+    ops = _ops()
+    from super_resolution_amd._lib import HAT_BF16
+    B, H, W, nout = geom
+    x = rnd(f"planes.x{geom}", (B, H, W, 64)).to(torch.bfloat16)
+    w = rnd(f"planes.w{geom}", (nout, 64, 3, 3), std=(9 * 64) ** -0.5)
+    b = rnd(f"planes.b{geom}", (nout,), std=0.1)
+    mean, scale = (0.4488, 0.4371, 0.4040), 0.5
+    assert ops.conv3x3_to_planes_supported(nout, 64, W, HAT_BF16)
+    wpk, b8 = ops.pack_cab_squeeze(w, b, dev)
+    out = torch.full((B, nout, H, W), 7.0, dtype=torch.float32, device=dev)
+    ops.conv3x3_to_planes(x.to(dev).contiguous(), wpk, b8, out, B=B, H=H, W=W, C_=64, ldx=64, n_out=nout, out_scale=scale,
+                          mean=mean, dtype=HAT_BF16)
+    torch.cuda.synchronize()
+    ref = F.conv2d(x.double().permute(0, 3, 1, 2), w.to(torch.bfloat16).double(), b.double(), padding=1) * scale
+    ref = ref + torch.tensor(mean[:nout], dtype=torch.float64).view(1, -1, 1, 1)
+    check(out.cpu(), ref.float(), "f32", f"conv_last planes {geom}", f32_tol=2e-5)
