@@ -355,6 +355,7 @@ int dispatch_nt(const HatConvDesc& d, size_t lds, hipStream_t s) {
     switch (d.nt) {
         case 1: return launch_conv<T, WAVES, PT, 1>(d, lds, s);
         case 4: return launch_conv<T, WAVES, PT, 4>(d, lds, s);
+        case 8: return launch_conv<T, WAVES, PT, 8>(d, lds, s);   // 256 outputs = 2 x 8 tiles exactly (the upsampler convs)
         case 9: return launch_conv<T, WAVES, PT, 9>(d, lds, s);
         case 12: return launch_conv<T, WAVES, PT, 12>(d, lds, s);
         default: return HAT_EINVAL;

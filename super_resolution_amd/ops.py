@@ -81,9 +81,9 @@ class PackedConv:
 
 
 def choose_nt(nout: int):
-    """n-tiles per slice in {12, 9, 4, 1}: least padded work, weighted by LDS fragment reads per MFMA."""
+    """n-tiles per slice in {12, 9, 8, 4, 1}: least padded work, weighted by LDS fragment reads per MFMA."""
     best = None
-    for nt in (12, 9, 4, 1):
+    for nt in (12, 9, 8, 4, 1):
         npad = -(-nout // (16 * nt)) * 16 * nt
         cost = npad * (nt + 2) / nt
         if best is None or cost < best[0]:

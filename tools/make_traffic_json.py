@@ -9,6 +9,7 @@ fdir, wdir, out, model, scale, H, W, dtype = sys.argv[1:9]
 BENCH_NAME = [  # rocprof kernel-name pattern -> the name bench.py prints
     (r"ffn_kernel", "ffn_kernel<__bf16>"), (r"ocab_attn", "ocab_attn_kernel<__bf16>"), (r"aggr_cab_kernel", "aggr_cab_kernel"),
     (r"pw_kernel.*ELi5E", "pw_kernel<__bf16, 9, 5>"), (r"pw_kernel.*ELi9E", "pw_kernel<__bf16, 9, 9>"),
+    (r"cab_squeeze_kernel(ILi5E|<5)", "cab_squeeze_kernel"), (r"cab_squeeze_kernel(ILi2E|<2)", "cab_squeeze_kernel<2, planes>"),
     (r"tap3_kernel.*41, 144", "tap3_kernel<__bf16, 1>"), (r"tap3_kernel.*ELi3ELi8E", "tap3_kernel<__bf16, 9>"),
     (r"conv_kernelIDF16bLi8ELi2ELi9E", "conv_kernel<__bf16, 8, 2, 9>"), (r"conv_kernelIDF16bLi8ELi2ELi1E", "conv_kernel<__bf16, 8, 2, 1>"),
     (r"conv_kernelIDF16bLi8ELi2ELi4E", "conv_kernel<__bf16, 8, 2, 4>"), (r"ln_kernel", "ln_kernel"),
