@@ -104,12 +104,18 @@ def main():
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the HIP path is the only path")
-    dev = torch.device("cuda", local_rank)
+    # HAT_BENCH_REHEARSE_ON_ONE_GPU=1: all ranks share cuda:0 and talk over gloo — only to exercise the N > 1 code path on
+    # a one-GPU box (the numbers mean nothing); the real run is one rank per GPU over RCCL
+    one_gpu = os.environ.get("HAT_BENCH_REHEARSE_ON_ONE_GPU") == "1"
+    dev = torch.device("cuda", 0 if one_gpu else local_rank)
     torch.cuda.set_device(dev)
     import torch.distributed as dist
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)  # RCCL
+        if one_gpu:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=dev)  # RCCL
 
     from super_resolution_amd import ops, synth, tile_parallel as tp
     from super_resolution_amd.registry import build_network
@@ -219,7 +225,8 @@ def main():
         try:
             with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01_hbm_traffic.json")) as f:
                 tr = json.load(f)
-            if tr.get("workload") == [args.model, s, H, W, args.dtype] and dom in tr.get("kernels", {}):
+            full_frame = world == 1 or args.mode == "frames"   # the recording is of full-frame launches, not of a tile's
+            if full_frame and tr.get("workload") == [args.model, s, H, W, args.dtype] and dom in tr.get("kernels", {}):
                 roofline["traffic"] = tr["kernels"][dom]["hbm_bytes_per_launch"]
                 roofline["traffic_source"] = "profiles/r01_hbm_traffic.json (FETCH_SIZE x2 + WRITE_SIZE, separate --pmc passes)"
         except (OSError, ValueError):
