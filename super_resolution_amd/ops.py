@@ -51,6 +51,10 @@ class profile:
         return False
 
 
+def profiling() -> bool:
+    return _prof is not None
+
+
 def _timed(name, flops, fn, tag="", nbytes=0.0):
     """nbytes: ALGORITHMIC HBM bytes of the launch (each operand read once, each result written once)."""
     if _prof is None:

@@ -199,3 +199,18 @@ def test_cfg5_hatl_batch32_samples_are_independent():
         torch.cuda.synchronize()
         err = max_abs(y[i:i + 1], yi)
         assert err <= 1e-6, f"sample {i}: batch vs alone differ by {err:.3e}"
+
+
+def test_hip_graph_replay_is_bit_identical():
+    """Optional `use_graph` mode: the forward (two streams, ~300 launches for HAT-S) captured once per shape and replayed
+    must reproduce the eager result bit for bit, also for a second input and after a shape change."""
+    dev = _dev()
+    net = build_net("hats_1g_x4", "bf16", dev)
+    xs = [synth.synth_input(31 + i, shp).to(dev) for i, shp in enumerate([(1, 3, 32, 48), (1, 3, 32, 48), (1, 3, 48, 32)])]
+    eager = [net(x).clone() for x in xs]
+    net.use_graph = True
+    for x, ye in zip(xs, eager):
+        yg = net(x)
+        torch.cuda.synchronize()
+        assert torch.equal(yg, ye)
+    assert torch.equal(net(xs[0]), eager[0])  # back to the first shape: re-captured
