@@ -269,6 +269,8 @@ class HATEngine:
         self._esc_conv(esc, w, n, B, H, W)
 
     def _side_stream(self):
+        if os.environ.get("HAT_ONE_STREAM") == "1":
+            return torch.cuda.current_stream()
         if getattr(self, "_s1", None) is None:
             self._s1 = torch.cuda.Stream(device=self.dev)
         return self._s1
