@@ -119,19 +119,20 @@ __global__ __launch_bounds__(1024) void esc_weights_kernel(const float* __restri
         for (int k = tid; k < Kpad; k += 1024) z[k] = to_T<T>(0.f);
         return;
     }
-    {   // fixed-order two-level reduction of the GAP partials: 64 strided parts, 4 independent chains each
+    {   // fixed-order two-level reduction of the GAP partials: 64 strided parts, 8 independent chains each, the 8 loads of
+        // an iteration unconditional (clamped + select) so that they are all in flight together — this kernel sits on the
+        // critical path in front of the 13x13 conv and is nothing but this latency
         const int ci = tid & 15, pp = tid >> 4;
-        float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+        float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
         const float* gp = gap_partial + (size_t)b * nblk * 16 + ci;
-        int k = pp;
-        for (; k + 192 < nblk; k += 256) {
-            s0 += gp[(size_t)k * 16];
-            s1 += gp[(size_t)(k + 64) * 16];
-            s2 += gp[(size_t)(k + 128) * 16];
-            s3 += gp[(size_t)(k + 192) * 16];
+        for (int k0 = pp; k0 < nblk; k0 += 512) {
+            float v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) v[u] = gp[(size_t)min(k0 + 64 * u, nblk - 1) * 16];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) acc[u] += (k0 + 64 * u < nblk) ? v[u] : 0.f;
         }
-        for (; k < nblk; k += 64) s0 += gp[(size_t)k * 16];
-        part[pp][ci] = (s0 + s1) + (s2 + s3);
+        part[pp][ci] = ((acc[0] + acc[1]) + (acc[2] + acc[3])) + ((acc[4] + acc[5]) + (acc[6] + acc[7]));
     }
     __syncthreads();
     if (tid < 16) {

@@ -324,9 +324,12 @@ class HATEngine:
                     # convs they do not depend on: esc_weights beside the CAB squeeze conv, cab_fold beside the 13x13 conv.
                     fo = hb["fold"]
                     s0, s1 = torch.cuda.current_stream(), self._side_stream()
-                    s1.wait_stream(s0)                              # n and its GAP partials are ready
-                    with torch.cuda.stream(s1):                     # chain 2: ESC weights -> 13x13 conv
-                        self._esc_w(esc, w, B, H, W, nblk)
+                    # The (tiny, latency-bound) ESC weight kernel goes first on the main stream: launched beside the
+                    # squeeze conv it waited for that kernel's waves to retire (they hold every register file for the
+                    # whole launch), and the 13x13 conv behind it started only then.
+                    self._esc_w(esc, w, B, H, W, nblk)
+                    s1.wait_stream(s0)                              # n and the 13x13 weights are ready
+                    with torch.cuda.stream(s1):                     # chain 2: 13x13 conv
                         self._esc_conv(esc, w, w["n"], B, H, W)
                     # chain 1: CAB squeeze conv -> fold
                     if w["sweep"]:
