@@ -525,6 +525,7 @@ extern "C" int hat_linear(const HatConvDesc* dp, void* stream) {
 #define HAT_PW_CASE(TT)                                                   \
     if (d.nt == 9 && ks == 5) return launch_pw<TT, 9, 5>(d, s);           \
     if (d.nt == 18 && ks == 5) return launch_pw<TT, 18, 5>(d, s);         \
+    if (d.nt == 23 && ks == 6) { if constexpr (sizeof(TT) == 2) return launch_pw<TT, 23, 6>(d, s); }  /* 180 -> 360, one slice */ \
     if (d.nt == 9 && ks == 9) return launch_pw<TT, 9, 9>(d, s);           \
     if (d.nt == 12 && ks == 6) return launch_pw<TT, 12, 6>(d, s);         \
     if (d.nt == 12 && ks == 12) return launch_pw<TT, 12, 12>(d, s);       \

@@ -403,7 +403,7 @@ def ffn(pf: PackedFFN, t_in, t_out, ln_g, ln_b, *, B: int, H: int, W: int, dtype
 # ------------------------------------------------------------------------------------------------
 # pointwise linear layers (hat_linear): fragment-packed weights, weight-stationary streaming GEMM
 # ------------------------------------------------------------------------------------------------
-_PW_SHAPES = {(9, 5), (18, 5), (9, 9), (12, 6), (12, 12), (4, 1), (4, 2)}  # (nt, ceil(Cin/32)) instantiated in hat_pw.hip
+_PW_SHAPES = {(9, 5), (18, 5), (9, 9), (12, 6), (23, 6), (12, 12), (4, 1), (4, 2)}  # (nt, ceil(Cin/32)) instantiated in hat_pw.hip
 
 
 def choose_nt_linear(nout: int, cin: int, dtype: int):
@@ -412,6 +412,8 @@ def choose_nt_linear(nout: int, cin: int, dtype: int):
     and these layers are HBM-bound."""
     if nout == 288 and -(-cin // 32) == 5 and dtype == HAT_BF16:
         return 18, 1
+    if nout == 360 and -(-cin // 32) == 6 and dtype == HAT_BF16:   # the same layers of the embed_dim-180 models: 23 n-tiles, 138 KB
+        return 23, 1
     return choose_nt(nout)
 
 
