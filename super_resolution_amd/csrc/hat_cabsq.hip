@@ -59,29 +59,32 @@ __global__ __launch_bounds__(256, KS > 2 ? 2 : 3) void cab_squeeze_kernel(const 
 #pragma unroll
     for (int ks = 0; ks < KS; ++ks) coff[ks] = (32 * ks + 8 * g + 8 <= C) ? 32 * ks + 8 * g : C - 8;
 
-    frag_t Bf[3][KS];
-    auto load_row = [&](int r, int d) {   // fragments of input row r shifted by dx = d - 1 (unconditional, clamped)
+    // activation fragments of NB input rows in flight: with 2 k-steps there are registers for a second row, which
+    // hides twice the load latency behind the (short) MFMA phase of a row
+    constexpr int NB = KS <= 2 ? 2 : 1;
+    frag_t Bf[NB][3][KS];
+    auto load_row = [&](int r, int d, frag_t (&B)[3][KS]) {   // fragments of input row r shifted by dx = d - 1 (unconditional, clamped)
         const int rc = min(max(r, 0), H - 1);
         const bf16_t* p = xb + ((size_t)rc * W + xc[d]) * ldx;
 #pragma unroll
-        for (int ks = 0; ks < KS; ++ks) Bf[d][ks] = M::load(p + coff[ks]);
+        for (int ks = 0; ks < KS; ++ks) B[d][ks] = M::load(p + coff[ks]);
     };
     f32x4 ring[3] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
     f32x4 csum = {0.f, 0.f, 0.f, 0.f};
 
     // one input row: S1 = slot of output row r + 1, S2 = slot of r - 1, S0 = slot of r (static indices: unrolled by 3)
-    auto step = [&](int r, f32x4& S1, f32x4& S2, f32x4& S0) {
+    auto step = [&](int r, f32x4& S1, f32x4& S2, f32x4& S0, frag_t (&B)[3][KS]) {
         const bool rok = r >= 0 && r < H;
 #pragma unroll
         for (int d = 0; d < 3; ++d) {
             const bool ok = rok && xok[d];
 #pragma unroll
             for (int ks = 0; ks < KS; ++ks) {
-                const frag_t bf = ok ? Bf[d][ks] : M::zero();
+                const frag_t bf = ok ? B[d][ks] : M::zero();
                 S1 = M::mma(A[2 * d][ks], bf, S1);
                 S2 = M::mma(A[2 * d + 1][ks], bf, S2);
             }
-            load_row(r + 1, d);   // the next row's fragments of this dx go out as soon as this row's are consumed
+            load_row(r + NB, d, B);   // the buffer's next row (r + NB), this dx, goes out as soon as this one is consumed
         }
         // output row y = r - 1: lower lane half of S2 + upper lane half of S0
         const int y = r - 1;
@@ -107,13 +110,22 @@ __global__ __launch_bounds__(256, KS > 2 ? 2 : 3) void cab_squeeze_kernel(const 
     };
 
 #pragma unroll
-    for (int d = 0; d < 3; ++d) load_row(y0 - 1, d);
-    // rows y0 - 1 .. y1, three per iteration so that the ring slots are compile-time registers:
-    // row r uses S1 = ring[(r + 1) % 3], S2 = ring[(r - 1) % 3], S0 = ring[r % 3] with r counted from y0 - 1 = "0"
-    for (int r = y0 - 1; r <= y1; r += 3) {
-        step(r, ring[1], ring[2], ring[0]);
-        if (r + 1 <= y1) step(r + 1, ring[2], ring[0], ring[1]);
-        if (r + 2 <= y1) step(r + 2, ring[0], ring[1], ring[2]);
+    for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+        for (int d = 0; d < 3; ++d) load_row(y0 - 1 + nb, d, Bf[nb]);
+    // rows y0 - 1 .. y1, three (six with two row buffers) per iteration so that ring slots and buffers are compile-time
+    // registers: row r uses S1 = ring[(r + 1) % 3], S2 = ring[(r - 1) % 3], S0 = ring[r % 3], r counted from y0 - 1 = "0"
+    // (the last group may run up to 3 NB - 1 rows past y1: their loads are clamped and their output rows are >= y1, i.e.
+    // not stored — cheaper than guards between the steps, at whose joins hipcc merges its s_waitcnt bookkeeping)
+    for (int r = y0 - 1; r <= y1; r += 3 * NB) {
+        step(r, ring[1], ring[2], ring[0], Bf[0]);
+        step(r + 1, ring[2], ring[0], ring[1], Bf[1 % NB]);
+        step(r + 2, ring[0], ring[1], ring[2], Bf[0]);
+        if constexpr (NB == 2) {
+            step(r + 3, ring[1], ring[2], ring[0], Bf[1]);
+            step(r + 4, ring[2], ring[0], ring[1], Bf[0]);
+            step(r + 5, ring[0], ring[1], ring[2], Bf[1]);
+        }
     }
     if (!NCHW && colsum != nullptr) {   // per-unit channel sums of the stored values (hat_cab_fold's ECA pooling)
 #pragma unroll
