@@ -81,6 +81,27 @@ def cpu_baseline(model, scale, crop, threads):
                       f"(cost is linear in pixels: fixed-size windows)"}
 
 
+def f32_path(args, cfg, x, dev, fl_frame):
+    """The same frame on the exact-fp32 kernel path (fp32 storage, v_mfma_f32_16x16x4_f32 = an fp32 fmaf chain): the
+    precision the reference itself computes in.  Timed OUTSIDE the bf16 region, after it; reported beside the headline."""
+    from super_resolution_amd import synth
+    from super_resolution_amd.registry import build_network
+    net = build_network(dict(type="HAT", upscale=args.scale, compute_dtype="f32", **cfg)).eval()
+    net.load_state_dict(synth.synth_state_dict(net.state_dict(), W_SEED), strict=True)
+    net = net.to(dev)
+    net(x)
+    torch.cuda.synchronize()
+    n = 2
+    t0 = time.perf_counter()
+    for _ in range(n):
+        net(x)
+    torch.cuda.synchronize()
+    ms = (time.perf_counter() - t0) / n * 1e3
+    tf = fl_frame / (ms * 1e-3) / 1e12
+    return {"dtype": "f32", "ms_per_frame": round(ms, 2), "frames_timed": n, "achieved_tflops": round(tf, 2),
+            "frac_of_f32_mfma_peak": round(tf / MFMA_PEAK_TFLOPS["f32"], 4), "peak_tflops": MFMA_PEAK_TFLOPS["f32"]}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -95,8 +116,24 @@ def main():
     ap.add_argument("--tile-pad", type=int, default=32)
     ap.add_argument("--cpu-crop", type=int, default=256, help="side of the crop timed on the CPU (0 disables the baseline)")
     ap.add_argument("--no-kernel-profile", action="store_true")
+    ap.add_argument("--no-f32-path", action="store_true", help="skip the exact-fp32 path timing reported beside the bf16 headline")
     args = ap.parse_args()
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # `python bench.py --gpus N` without a launcher: start the N ranks ourselves, as children, BEFORE anything in
+        # this process touches the GPU (a process that has initialised HIP must never exec another program on this
+        # pool), relay their output (rank 0 prints the one JSON line) and exit with their code.
+        import socket
+        import subprocess
+        with socket.socket() as sk:
+            sk.bind(("127.0.0.1", 0))
+            port = sk.getsockname()[1]
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+               "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+        env = dict(os.environ)
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        env.setdefault("OMP_NUM_THREADS", "4")
+        raise SystemExit(subprocess.run(cmd, env=env).returncode)
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -223,12 +260,14 @@ def main():
         # HBM bytes per launch from the PMC counters: measured in separate rocprofv3 --pmc passes (profiles/README.md)
         # and recorded in profiles/; quoted only when the recording is of this exact workload
         try:
-            with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01_hbm_traffic.json")) as f:
+            pdir = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles")
+            tfile = sorted(f for f in os.listdir(pdir) if f.endswith("_hbm_traffic.json"))[-1]   # the latest round's recording
+            with open(os.path.join(pdir, tfile)) as f:
                 tr = json.load(f)
             full_frame = world == 1 or args.mode == "frames"   # the recording is of full-frame launches, not of a tile's
             if full_frame and tr.get("workload") == [args.model, s, H, W, args.dtype] and dom in tr.get("kernels", {}):
                 roofline["traffic"] = tr["kernels"][dom]["hbm_bytes_per_launch"]
-                roofline["traffic_source"] = "profiles/r01_hbm_traffic.json (FETCH_SIZE x2 + WRITE_SIZE, separate --pmc passes)"
+                roofline["traffic_source"] = f"profiles/{tfile} (FETCH_SIZE x2 + WRITE_SIZE, separate --pmc passes)"
         except (OSError, ValueError):
             pass
     if world > 1:
@@ -249,6 +288,8 @@ def main():
             "roofline": roofline,
             "kernels": kernels,
         }
+        if world == 1 and args.dtype == "bf16" and not args.no_f32_path:
+            res["path_f32"] = f32_path(args, cfg, x, dev, fl_frame)
         if world == 1 and args.cpu_crop > 0:
             # the GPU box gives one GPU a share of 16 host cores; more threads than that only oversubscribe
             cores = min(16, len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1))

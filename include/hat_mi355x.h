@@ -162,6 +162,14 @@ int hat_layernorm(const float* x, void* y, const float* gamma, const float* beta
                   int32_t dtype, void* stream);
 
 /*
+ * out[b][i] = a[b][i] + c[b * c_bstride + i], i < n (fp32, n % 4 == 0; out may alias a).  The plain adds of the
+ * reference that no producing kernel can absorb: the absolute position embedding (hat_arch.py:837-838,
+ * c_bstride = 0: broadcast over the batch) and the residuals around nn.Identity when
+ * resi_connection == 'identity' (:545-546 with :556, :748 with :854).
+ */
+int hat_add_f32(const float* a, const float* c, float* out, int32_t B, int64_t n, int64_t c_bstride, void* stream);
+
+/*
  * ESC per-sample conv weights (esc_arch.py:95-100,121-123): p = mean(gap partials);
  * dk = W2 * gelu(W1 * p + b1) + b2 (pdim*9 values); Wp[b][co][tap*Cin_p + ci] =
  * T( plk_packed[co][tap*Cin_p+ci] + (co == ci && tap in central 3x3 ? dk[co*9 + ..] : 0) ).

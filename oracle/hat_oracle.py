@@ -336,6 +336,8 @@ def state_dict_spec(cfg: dict) -> Dict[str, tuple]:
         conv(p + ".plk.dwc_proj.3", pdim * 9, pdim // 2, 1)
         conv(p + ".aggr", C, C, 1)
 
+    if cfg["ape"]:  # own parameters come before own buffers in Module.state_dict (hat_arch.py:699-702)
+        add("absolute_pos_embed", (1, (cfg["img_size"] // cfg.get("patch_size", 1)) ** 2, C))
     add("relative_position_index_SA", (ws * ws, ws * ws), i64)
     add("relative_position_index_OCA", (ws * ws, wse * wse), i64)
     conv("conv_first", C, cfg["in_chans"], 3)

@@ -13,8 +13,8 @@ no CPU path: a CPU tensor or a missing libhat_mi355x.so raises.
 """
 from __future__ import annotations
 
+import collections
 import math
-
 import os
 
 import torch
@@ -233,9 +233,11 @@ class HAT(nn.Module):
         self.apply(self._init_weights)
         self._engine = None
         self._engine_key = None
+        self._wver = 0   # bumped whenever the parameters may have changed (load_state_dict, .to()/.cuda()/..., explicit)
         # extra (non-reference) switch: replay the forward as a HIP graph (also HAT_GRAPH=1 in the environment)
         self.use_graph = bool(kwargs.get("use_graph", False)) or os.environ.get("HAT_GRAPH") == "1"
-        self._graphs, self._graph_engine = {}, None
+        self._graphs, self._graph_engine = collections.OrderedDict(), None
+        self._graph_max = int(os.environ.get("HAT_GRAPH_CACHE", "4"))
 
     def _init_weights(self, m):  # hat_arch.py:761-768
         if isinstance(m, nn.Linear):
@@ -260,15 +262,42 @@ class HAT(nn.Module):
         self._engine = None
         return self
 
+    # The engine holds PACKED copies of the parameters.  It is rebuilt when the weights version changes: the version is
+    # bumped by every bulk path that rewrites parameters — load_state_dict, and _apply (.to / .cuda / .float / ...) —
+    # instead of walking ~900 parameters on every forward (that walk alone was ~1 ms, a fifth of a 64x64 forward).
+    # Code that edits parameter tensors in place must call `mark_weights_changed()` (HAT_STRICT_WEIGHTS=1 restores the
+    # per-forward walk over (data_ptr, _version) for debugging).
+    def mark_weights_changed(self):
+        self._wver += 1
+        return self
+
+    def load_state_dict(self, *args, **kwargs):
+        r = super().load_state_dict(*args, **kwargs)
+        self._wver += 1
+        return r
+
+    def _apply(self, fn, *args, **kwargs):
+        r = super()._apply(fn, *args, **kwargs)
+        self._wver = getattr(self, "_wver", 0) + 1
+        return r
+
     def _weights_key(self, device):
-        return (str(device), self.compute_dtype, tuple((p.data_ptr(), p._version) for p in self.parameters()))
+        key = (str(device), self.compute_dtype, self._wver)
+        if os.environ.get("HAT_STRICT_WEIGHTS") == "1":
+            key += tuple((p.data_ptr(), p._version) for p in self.parameters())
+        return key
 
     def engine(self, device=None):
         """The packed-weight engine for the current parameters (re-packed when they change)."""
         from ..engine import HATEngine
-        device = device or next(self.parameters()).device
+        device = torch.device(device) if device is not None else self.conv_first.weight.device
+        if device.type == "cuda" and device.index is None:
+            device = torch.device("cuda", torch.cuda.current_device())
         key = self._weights_key(device)
         if self._engine is None or self._engine_key != key:
+            if self.conv_first.weight.device != device:
+                raise RuntimeError(f"input is on {device} but the parameters are on {self.conv_first.weight.device}: "
+                                   f"move the module first (net.to('{device}'))")
             self._engine = HATEngine(self.cfg, self.state_dict(), device, self.compute_dtype)
             self._engine_key = key
         return self._engine
@@ -291,24 +320,30 @@ class HAT(nn.Module):
         Removes the host launch path and most inter-kernel gaps; matters most for small frames / tiles."""
         eng = self.engine(x.device)
         if self._graph_engine is not eng:
-            self._graphs, self._graph_engine = {}, eng
+            self._graphs, self._graph_engine = collections.OrderedDict(), eng
         key = (tuple(x.shape), x.dtype)
-        ent = self._graphs.get(key)
-        if ent is None:
-            self._graphs.clear()  # one shape at a time: each graph pins a full workspace and output
-            sx = x.detach().clone()
-            cur = torch.cuda.current_stream()
-            side = torch.cuda.Stream(device=x.device)
-            side.wait_stream(cur)
-            with torch.cuda.stream(side):
-                for _ in range(2):
-                    eng.forward(sx)
-            cur.wait_stream(side)
-            g = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g):
-                sy = eng.forward(sx)
-            ent = self._graphs[key] = (g, sx, sy)
-        g, sx, sy = ent
-        sx.copy_(x)
-        g.replay()
-        return sy.to(x.dtype, copy=True)
+        with torch.cuda.device(x.device):
+            ent = self._graphs.get(key)
+            if ent is None:
+                sx = x.detach().clone()
+                cur = torch.cuda.current_stream(x.device)
+                side = torch.cuda.Stream(device=x.device)
+                side.wait_stream(cur)
+                with torch.cuda.stream(side):
+                    for _ in range(2):
+                        eng.forward(sx)
+                cur.wait_stream(side)
+                g = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g):
+                    sy = eng.forward(sx)
+                # the graph bakes in raw pointers into the engine's workspace of this shape: the entry keeps that
+                # workspace alive even after the engine's own LRU has dropped it
+                ent = self._graphs[key] = (g, sx, sy, eng._workspace(*x.shape[:1], *x.shape[2:]))
+                while len(self._graphs) > self._graph_max:
+                    self._graphs.popitem(last=False)
+            else:
+                self._graphs.move_to_end(key)
+            g, sx, sy, _ = ent
+            sx.copy_(x)
+            g.replay()
+            return sy.to(x.dtype, copy=True)

@@ -493,5 +493,25 @@ extern "C" int hat_dwconv_gate(const void* u, const float* wdw, const float* bdw
     return hat_check_launch();
 }
 
+namespace {
+__global__ __launch_bounds__(256) void add_f32_kernel(const float* __restrict__ a, const float* __restrict__ c, float* out,
+                                                      long n4, long n, long c_bstride) {
+    const int b = blockIdx.y;
+    const f32x4* av = reinterpret_cast<const f32x4*>(a + (size_t)b * n);
+    const f32x4* cv = reinterpret_cast<const f32x4*>(c + (size_t)b * c_bstride);
+    f32x4* ov = reinterpret_cast<f32x4*>(out + (size_t)b * n);
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long)gridDim.x * 256) ov[i] = av[i] + cv[i];
+}
+}  // namespace
+
+extern "C" int hat_add_f32(const float* a, const float* c, float* out, int32_t B, int64_t n, int64_t c_bstride, void* stream) {
+    if (!a || !c || !out || B < 1 || n < 4 || n % 4 || c_bstride < 0 || c_bstride % 4) return HAT_EINVAL;
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    const long n4 = n / 4;
+    const int blocks = (int)((n4 + 255) / 256 < 4096 ? (n4 + 255) / 256 : 4096);
+    HAT_LAUNCH(add_f32_kernel, dim3(blocks, B), dim3(256), 0, s, a, c, out, n4, (long)n, (long)c_bstride);
+    return hat_check_launch();
+}
+
 extern "C" int hat_abi_version(void) { return HAT_ABI_VERSION; }
 extern "C" const char* hat_target_arch(void) { return "gfx950"; }

@@ -57,7 +57,13 @@ class FolderDataset:
     def __getitem__(self, i):
         d = {"lq": read_image(self.lq[i]).unsqueeze(0), "lq_path": [self.lq[i]]}
         if self.gt is not None:
-            d["gt"] = read_image(self.gt[i]).unsqueeze(0)
+            gt = read_image(self.gt[i]).unsqueeze(0)
+            # test phase: GT cropped to lq size x scale (paired_image_dataset.py:92-95) so that a GT whose size is not an
+            # exact multiple of the LQ size is still scored, as the reference does
+            s = int(self.opt.get("scale", 0) or 0)
+            if s > 0 and self.opt.get("phase", "test") != "train":
+                gt = gt[..., :d["lq"].shape[-2] * s, :d["lq"].shape[-1] * s]
+            d["gt"] = gt
             d["gt_path"] = [self.gt[i]]
         return d
 

@@ -15,8 +15,10 @@ T = bf16 (performance path) or fp32 (exact-fp32 parity path).
 """
 from __future__ import annotations
 
+import collections
 import math
 import os
+import threading
 from typing import Dict, Optional
 
 import torch
@@ -63,11 +65,10 @@ class HATEngine:
     def __init__(self, cfg: dict, state_dict: Dict[str, torch.Tensor], device, dtype: str = "bf16"):
         if cfg.get("upsampler") != "pixelshuffle":
             raise NotImplementedError("only upsampler='pixelshuffle' is on the hot path (all shipped test YAMLs)")
-        if cfg.get("resi_connection", "1conv") != "1conv":
-            raise NotImplementedError("resi_connection='identity' is not implemented (no shipped config uses it)")
-        if cfg.get("ape", False):
-            raise NotImplementedError("ape=True is not implemented (no shipped config uses it)")
+        if cfg.get("resi_connection", "1conv") not in ("1conv", "identity"):
+            raise ValueError(f"Unknown resi_connection: {cfg.get('resi_connection')}")   # hat_arch.py:547-548, :750-751
         self.cfg = cfg
+        self.identity = cfg.get("resi_connection", "1conv") == "identity"
         self.dev = torch.device(device)
         if self.dev.type != "cuda":
             raise RuntimeError("HATEngine needs a GPU device: there is no CPU path")
@@ -77,11 +78,15 @@ class HATEngine:
         self.ws = cfg["window_size"]
         self.wse = self.ws + int(cfg["overlap_ratio"] * self.ws)
         self.scale = cfg["upscale"]
-        self._ws_cache = {}
+        # per-shape workspaces, least recently used first; tiled inference alternates between a few shapes (interior /
+        # edge / corner tiles), so a small LRU allocates and zero-fills each of them once
+        self._ws_cache = collections.OrderedDict()
+        self._ws_max = int(os.environ.get("HAT_WS_CACHE", "12"))
+        self._ws_max_bytes = int(float(os.environ.get("HAT_WS_CACHE_GIB", "96")) * 2 ** 30)
+        self._lock = threading.Lock()   # one forward at a time per engine: the workspace and side stream are shared state
         ops._lib.load()
         # fused FFN kernel (hat_ffn) for the shapes it is instantiated for; HAT_NO_FUSED_FFN=1 forces the
         # unfused kernel sequence (fc1 -> dw+gate -> fc2), kept for A/B validation of the fusion
-        import os
         self.fuse_ffn = ops.ffn_supported(self.C) and os.environ.get("HAT_NO_FUSED_FFN", "0") != "1"
         self._pack(state_dict)
 
@@ -118,6 +123,7 @@ class HATEngine:
         vec = lambda k: sd[k].detach().to(**f32).contiguous()
         self.conv_first = P("conv_first.weight", "conv_first.bias")
         self.pe_norm = (vec("patch_embed.norm.weight"), vec("patch_embed.norm.bias")) if cfg.get("patch_norm", True) else None
+        self.ape = vec("absolute_pos_embed").reshape(-1) if cfg.get("ape", False) else None   # (num_patches * C,)  :699-702
         self.layers = []
         ws, wse = self.ws, self.wse
         M = ws + wse - 1
@@ -174,10 +180,10 @@ class HATEngine:
                 oc["esc"] = _ESC(sd, p + ".esc_core", p + ".esc_plk", cfg["ocab_esc_pdim"], cfg["ocab_esc_kernel"], C, dt, dev)
                 oc["esc"].aggr = self._lin(sd, *oc["esc"].aggr_keys)
             L["ocab"] = oc
-            L["conv"] = P(f"layers.{g}.conv.weight", f"layers.{g}.conv.bias")
+            L["conv"] = None if self.identity else P(f"layers.{g}.conv.weight", f"layers.{g}.conv.bias")
             self.layers.append(L)
         self.norm = (vec("norm.weight"), vec("norm.bias"))
-        self.conv_after_body = P("conv_after_body.weight", "conv_after_body.bias")
+        self.conv_after_body = None if self.identity else P("conv_after_body.weight", "conv_after_body.bias")
         self.conv_before_up = P("conv_before_upsample.0.weight", "conv_before_upsample.0.bias")
         self.ups = []
         s = self.scale
@@ -209,8 +215,8 @@ class HATEngine:
         key = (B, H, W)
         ws = self._ws_cache.get(key)
         if ws is not None:
+            self._ws_cache.move_to_end(key)
             return ws
-        self._ws_cache.clear()  # one shape at a time: frames are big
         C, dev, T = self.C, self.dev, self.tdt
         N = H * W
         mid = self.layers[0]["habs"][0]["cab0"].nout if self.layers and self.layers[0]["habs"] else 8
@@ -249,7 +255,13 @@ class HATEngine:
         for _, r in self.ups:
             h, wd = h * r, wd * r
             w["ups"].append(z(B, h * wd, 64))
+        w["bytes"] = sum(t.numel() * t.element_size() for v in w.values() for t in (v if isinstance(v, list) else [v])
+                         if isinstance(t, torch.Tensor))
         self._ws_cache[key] = w
+        self.ws_allocations = getattr(self, "ws_allocations", 0) + 1
+        while len(self._ws_cache) > 1 and (len(self._ws_cache) > self._ws_max
+                                           or sum(v["bytes"] for v in self._ws_cache.values()) > self._ws_max_bytes):
+            self._ws_cache.popitem(last=False)   # graphs captured on an evicted workspace keep their own reference
         return w
 
     # ------------------------------------------------------------------------------------------
@@ -270,7 +282,7 @@ class HATEngine:
 
     def _side_stream(self):
         if os.environ.get("HAT_ONE_STREAM") == "1":
-            return torch.cuda.current_stream()
+            return torch.cuda.current_stream(self.dev)
         if getattr(self, "_s1", None) is None:
             self._s1 = torch.cuda.Stream(device=self.dev)
         return self._s1
@@ -278,6 +290,14 @@ class HATEngine:
     def forward(self, x: torch.Tensor) -> torch.Tensor:
         if not x.is_cuda:
             raise RuntimeError("HAT forward needs a device tensor: the HIP path is the only path")
+        if x.device != self.dev:
+            raise RuntimeError(f"input is on {x.device} but this engine's weights and workspace live on {self.dev}")
+        # kernels are enqueued on the CURRENT stream of the engine's device: make that device current for the launches
+        # (the C side never switches devices), and serialise callers: workspace and side stream are per-engine state
+        with self._lock, torch.cuda.device(self.dev):
+            return self._forward(x)
+
+    def _forward(self, x: torch.Tensor) -> torch.Tensor:
         if x.dim() != 4 or x.shape[1] != self.cfg["in_chans"]:
             raise RuntimeError(f"expected (B,{self.cfg['in_chans']},H,W), got {tuple(x.shape)}")
         B, _, H, W = x.shape
@@ -304,7 +324,12 @@ class HATEngine:
         if self.pe_norm is not None:  # patch_embed + LN                                 :836
             ln(w["f0"], tA, self.pe_norm, out_f32=True)
         else:
-            tA.copy_(w["f0"])
+            tA.copy_(w["f0"])        # device-to-device copy on the current stream
+        if self.ape is not None:      # x + absolute_pos_embed (1, num_patches, C)          :837-838
+            if self.ape.numel() != N * C:
+                raise RuntimeError(f"absolute_pos_embed holds {self.ape.numel() // C} positions but the input has {N} "
+                                   f"pixels (ape=True fixes the input size to img_size, hat_arch.py:699-702)")
+            ops.add_f32(tA, self.ape, tA, B=B, n=N * C, c_bstride=0)
         LNB = ops.layernorm_blocks()
         for L in self.layers:
             t = tA            # current value of the residual stream (tA must survive until the RHAG tail)
@@ -323,7 +348,7 @@ class HATEngine:
                     # The two tiny per-sample kernels (one workgroup each, latency-bound) run on a side stream next to the
                     # convs they do not depend on: esc_weights beside the CAB squeeze conv, cab_fold beside the 13x13 conv.
                     fo = hb["fold"]
-                    s0, s1 = torch.cuda.current_stream(), self._side_stream()
+                    s0, s1 = torch.cuda.current_stream(self.dev), self._side_stream()
                     # The (tiny, latency-bound) ESC weight kernel goes first on the main stream: launched beside the
                     # squeeze conv it waited for that kernel's waves to retire (they hold every register file for the
                     # whole launch), and the 13x13 conv behind it started only then.
@@ -386,7 +411,7 @@ class HATEngine:
                 self._esc_lk(esc, w, w["n"], B, H, W, nblk)
                 self._run_lin(esc.aggr, w["n"], w["yesc"], **geo, ldx=ldc, ldo=ldc, x0=w["y16"], c_split=esc.pdim, ldx0=16)
                 kv_src = w["yesc"]
-            s0, s1 = torch.cuda.current_stream(), self._side_stream()   # q and kv projections are independent
+            s0, s1 = torch.cuda.current_stream(self.dev), self._side_stream()   # q and kv projections are independent
             s1.wait_stream(s0)
             with torch.cuda.stream(s1):
                 self._run_lin(oc["q"], w["n"], w["q"], **geo, ldx=ldc, ldo=ldc)
@@ -404,11 +429,19 @@ class HATEngine:
             self._run_lin(oc["mlp0"], w["n"], w["g"], **geo, ldx=ldc, ldo=w["g"].shape[2], act=ACT_GELU)
             self._run_lin(oc["mlp2"], w["g"], tout, **geo, ldx=w["g"].shape[2], ldo=C, out_mode=O_NHWC_F32, r1=tout, ldr1=C)
             # RHAG tail: conv3x3 + group residual, written over the group input             :556
-            ops.conv(L["conv"], tout, tA, **geo, ldx=C, ldo=C, x_mode=X_NHWC_F32, out_mode=O_NHWC_F32, r1=tA, ldr1=C)
-        ln(tA, w["n"], self.norm)  # final LN                                             :844
-        # conv_after_body + f0 ; conv_before_upsample + LeakyReLU                          :854-855
-        ops.conv(self.conv_after_body, w["n"], w["c2"], **geo, ldx=ldc, ldo=ldc, r1=w["f0"], ldr1=C)
-        ops.conv(self.conv_before_up, w["c2"], w["fb"], **geo, ldx=ldc, ldo=64, act=ACT_LRELU)
+            if L["conv"] is None:  # resi_connection == 'identity': group(x) + x                 :545-546
+                ops.add_f32(tout, tA, tA, B=B, n=N * C)
+            else:
+                ops.conv(L["conv"], tout, tA, **geo, ldx=C, ldo=C, x_mode=X_NHWC_F32, out_mode=O_NHWC_F32, r1=tA, ldr1=C)
+        # final LN; conv_after_body + f0 ; conv_before_upsample + LeakyReLU                :844, :854-855
+        if self.conv_after_body is None:   # nn.Identity: LN(t) + f0 in fp32, read as such by the next conv      :748
+            ln(tA, tB, self.norm, out_f32=True)
+            ops.add_f32(tB, w["f0"], tB, B=B, n=N * C)
+            ops.conv(self.conv_before_up, tB, w["fb"], **geo, ldx=C, ldo=64, x_mode=X_NHWC_F32, act=ACT_LRELU)
+        else:
+            ln(tA, w["n"], self.norm)
+            ops.conv(self.conv_after_body, w["n"], w["c2"], **geo, ldx=ldc, ldo=ldc, r1=w["f0"], ldr1=C)
+            ops.conv(self.conv_before_up, w["c2"], w["fb"], **geo, ldx=ldc, ldo=64, act=ACT_LRELU)
         src, h, wd = w["fb"], H, W
         for (pw, rr), dst in zip(self.ups, w["ups"]):  # conv + PixelShuffle                :593-605
             ops.conv(pw, src, dst, B=B, H=h, W=wd, dtype=dt, ldx=64, ldo=64, out_mode=O_PIXSHUF_T, ps_r=rr)

@@ -181,6 +181,13 @@ def layernorm(x: torch.Tensor, y: torch.Tensor, gamma: torch.Tensor, beta: torch
                           _stream()), "hat_layernorm"))
 
 
+def add_f32(a: torch.Tensor, c: torch.Tensor, out: torch.Tensor, *, B: int, n: int, c_bstride: Optional[int] = None):
+    """out[b] = a[b] + c[b] (c_bstride = n) or + c (c_bstride = 0: broadcast over the batch); fp32."""
+    lib = _lib.load()
+    cb = n if c_bstride is None else c_bstride
+    _timed("add_f32_kernel", 0.0, lambda: _lib.check(lib.hat_add_f32(_ptr(a), _ptr(c), _ptr(out), B, n, cb, _stream()), "hat_add_f32"))
+
+
 def esc_weights(gap: torch.Tensor, nblk: int, npix: int, w1, b1, w2, b2, plk_packed, w_out, *, B: int, pdim: int,
                 ksize: int, kpad: int, dtype: int):
     lib = _lib.load()

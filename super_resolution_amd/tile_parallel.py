@@ -107,6 +107,22 @@ def tile_forward(img: torch.Tensor, net: Callable, scale: int, tiles: Sequence[T
     return out
 
 
+_XBUF = {}
+
+
+def _exchange_buffers(shape, world, dtype, device):
+    """send / recv staging of the all-gather, allocated once per (shape, world, dtype, device) and reused by every step
+    (cores smaller than the slot leave stale padding behind them; the unpack below never reads it)."""
+    key = (tuple(shape), world, dtype, str(device))
+    buf = _XBUF.get(key)
+    if buf is None:
+        _XBUF.clear()
+        send = torch.zeros(shape, dtype=dtype, device=device)
+        recv = torch.empty((world * shape[0],) + tuple(shape[1:]), dtype=dtype, device=device)
+        buf = _XBUF[key] = (send, recv)
+    return buf
+
+
 def tile_parallel_forward(img: torch.Tensor, net: Callable, scale: int, tiles: Sequence[Tile], group=None,
                           out: Optional[torch.Tensor] = None) -> torch.Tensor:
     """Every rank holds the full LR frame `img` (11 MB at 720p) and the full weights; rank r runs the
@@ -119,11 +135,10 @@ def tile_parallel_forward(img: torch.Tensor, net: Callable, scale: int, tiles: S
     slots = max(len(o) for o in owned)
     mh = max(t.y1 - t.y0 for t in tiles) * scale
     mw = max(t.x1 - t.x0 for t in tiles) * scale
-    send = torch.zeros((slots, b, c, mh, mw), dtype=img.dtype, device=img.device)
+    send, recv = _exchange_buffers((slots, b, c, mh, mw), world, img.dtype, img.device)
     for s, i in enumerate(owned[rank]):
         o = run_tile(img, net, tiles[i], scale)
         send[s, :, :, :o.shape[2], :o.shape[3]] = o
-    recv = torch.empty((world * slots,) + tuple(send.shape[1:]), dtype=img.dtype, device=img.device)
     dist.all_gather_into_tensor(recv, send, group=group)  # concatenation along dim 0, rank-major
     recv = recv.view((world, slots) + tuple(send.shape[1:]))
     if out is None:

@@ -14,7 +14,7 @@ from helpers import GOLDEN, W_SEED, WMSA_CASES, X_SEED, cfg_of, golden, max_abs,
 TOL = 1e-5  # restatement vs reference <= 1e-5 max-abs, fp32
 
 
-@pytest.mark.parametrize("name", ["tiny_x2", "tiny_ocabesc_x2", "HAT-S_x2", "HAT-S_x4", "HAT_x4", "HAT-L_x4"])
+@pytest.mark.parametrize("name", ["tiny_x2", "tiny_ocabesc_x2", "tiny_identity_ape_x2", "HAT-S_x2", "HAT-S_x4", "HAT_x4", "HAT-L_x4"])
 def test_state_dict_surface(name):
     with open(os.path.join(GOLDEN, "state_dict_surface.json")) as f:
         surf = json.load(f)
@@ -36,7 +36,7 @@ def test_rpi_tables_bit_exact(ws, file):
     assert int(oca.min()) < 0  # negative indices are part of the contract
 
 
-@pytest.mark.parametrize("name", ["tiny_x2", "tiny_x4", "tiny_x3", "tiny_ocabesc_x2", "hats_1g_x4", "hat_1g_x2"])
+@pytest.mark.parametrize("name", ["tiny_x2", "tiny_x4", "tiny_x3", "tiny_ocabesc_x2", "tiny_identity_ape_x2", "hats_1g_x4", "hat_1g_x2"])
 def test_whole_model(name):
     g = golden(f"whole_{name}.npz")
     cfg, sd = oracle_sd(name)
