@@ -299,6 +299,20 @@ typedef struct HatFfnDesc {
 int hat_ffn_tiles(const HatFfnDesc* d, int32_t* tiles_out);
 int hat_ffn(const HatFfnDesc* d, void* stream);
 
+/*
+ * Second-generation fused feed-forward half for embed_dim 144 / bf16 (same HatFfnDesc, same tile geometry and outputs as
+ * hat_ffn; m_in must be NULL): the hidden tensor lives on chip as FP16 (fc1 accumulators converted round-toward-zero:
+ * saturating), the depthwise 3x3 and the gate run as packed-fp16 VALU, fc2 is an fp16 MFMA.  Different packing:
+ *   w1f [chunk][4][5][64 lanes][8] bf16 : fc1 rows {a: 32c..32c+31 | gate: hid+32c..} of chunk c, A-fragment order,
+ *                                         K = 144 zero padded to 160 (NO bias column)
+ *   b1  [chunk][64] fp32                : fc1 bias of the chunk's rows in the same order (the MFMA C operand)
+ *   dww [chunk][4 groups][10][16] fp16  : depthwise weights of hidden units 32c+8g..+7 per tap 0..8 and the depthwise
+ *                                         BIAS as "tap 9": eight a-unit values then eight gate-unit values
+ *   w2f [chunk][9][64 lanes][8] fp16    : fc2 columns 32c..32c+31 in natural k order (k = 8*(lane>>4) + j)
+ *   b2  [144] fp32.  dwb is not read.  HAT_EUNSUPPORTED unless C == 144 and dtype == HAT_BF16.
+ */
+int hat_ffn2(const HatFfnDesc* d, void* stream);
+
 int hat_abi_version(void);
 /* name of the architecture the code objects in this library were compiled for ("gfx950") */
 const char* hat_target_arch(void);

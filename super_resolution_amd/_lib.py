@@ -88,6 +88,7 @@ SIGNATURES = {
     "hat_aggr_cab": (C.c_int, [C.POINTER(HatAggrCabDesc), C.c_void_p]),
     "hat_ffn_tiles": (C.c_int, [C.POINTER(HatFfnDesc), C.POINTER(C.c_int32)]),
     "hat_ffn": (C.c_int, [C.POINTER(HatFfnDesc), C.c_void_p]),
+    "hat_ffn2": (C.c_int, [C.POINTER(HatFfnDesc), C.c_void_p]),
     "hat_layernorm_blocks": (C.c_int, []),
     "hat_layernorm": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int64,
                                 C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_void_p]),

@@ -158,8 +158,14 @@ class HATEngine:
                 hb["dw_w"] = sd[p + ".mlp.dw.weight"].detach().to(**f32).reshape(hid2, 9).t().contiguous()  # [9][2*hid]
                 hb["dw_b"] = vec(p + ".mlp.dw.bias")
                 if self.fuse_ffn:
-                    hb["ffn"] = ops.pack_ffn(sd[p + ".mlp.fc1.weight"], sd[p + ".mlp.fc1.bias"], sd[p + ".mlp.dw.weight"],
-                                             sd[p + ".mlp.dw.bias"], sd[p + ".mlp.fc2.weight"], sd[p + ".mlp.fc2.bias"], dt, dev)
+                    fw = [sd[p + k] for k in (".mlp.fc1.weight", ".mlp.fc1.bias", ".mlp.dw.weight", ".mlp.dw.bias",
+                                              ".mlp.fc2.weight", ".mlp.fc2.bias")]
+                    # hat_ffn2 (fp16 hidden tensor, depthwise conv on the packed-fp16 VALU) where it is built; HAT_FFN_V1=1
+                    # keeps the first-generation kernel for A/B runs
+                    if ops.ffn2_supported(C, hid2 // 2, dt) and os.environ.get("HAT_FFN_V1") != "1":
+                        hb["ffn"] = ops.pack_ffn2(*fw, dev)
+                    else:
+                        hb["ffn"] = ops.pack_ffn(*fw, dt, dev)
                 L["habs"].append(hb)
             p = f"layers.{g}.residual_group.overlap_attn"
             d = C // heads

@@ -366,6 +366,50 @@ def pack_ffn(fc1_w, fc1_b, dw_w, dw_b, fc2_w, fc2_b, dtype: int, device) -> Pack
     return p
 
 
+def ffn2_supported(C_: int, hid: int, dtype: int) -> bool:
+    """Shapes hat_ffn2 (fp16 hidden tensor, VALU depthwise conv) is built for."""
+    return C_ == 144 and hid % 32 == 0 and dtype == HAT_BF16
+
+
+def pack_ffn2(fc1_w, fc1_b, dw_w, dw_b, fc2_w, fc2_b, device) -> PackedFFN:
+    """GatedDconvFFN weights (hat_arch.py:99-104) in hat_ffn2's layouts (include/hat_mi355x.h)."""
+    f = lambda t: t.detach().to(torch.float32).cpu()
+    W1, b1, Wd, bd, W2, b2 = f(fc1_w), f(fc1_b), f(dw_w).reshape(-1, 9), f(dw_b), f(fc2_w), f(fc2_b)
+    C_, hid = W2.shape
+    assert W1.shape == (2 * hid, C_) and Wd.shape[0] == 2 * hid and hid % 32 == 0 and C_ == 144
+    chunks, ks, nt = hid // 32, 5, 9
+    lane = torch.arange(64)
+    n16, g4, j8 = lane & 15, lane >> 4, torch.arange(8)
+    # chunk-local channel nl in [0, 64): a-unit 32c + nl (nl < 32) or gate-unit 32c + nl - 32 -> fc1 row
+    nl = torch.arange(64)
+    rows = torch.where(nl[None, :] < 32, torch.arange(chunks)[:, None] * 32 + nl[None, :],
+                       hid + torch.arange(chunks)[:, None] * 32 + nl[None, :] - 32)              # (chunks, 64)
+    W1p = torch.zeros(2 * hid, ks * 32)
+    W1p[:, :C_] = W1
+    r = rows.reshape(chunks, 4, 16)[:, :, None, n16, None].expand(chunks, 4, ks, 64, 8)
+    col = (torch.arange(ks)[None, None, :, None, None] * 32 + 8 * g4[None, None, None, :, None] + j8).expand(chunks, 4, ks, 64, 8)
+    w1f = W1p[r, col]
+    b1c = b1[rows]                                                                               # (chunks, 64)
+    # depthwise: [chunk][g][tap 0..8, bias][a-units 8g..8g+7 | gate-units 8g..8g+7]
+    Wd10 = torch.cat([Wd, bd[:, None]], dim=1)                                                    # (2*hid, 10)
+    unit = (torch.arange(chunks)[:, None, None] * 32 + 8 * torch.arange(4)[None, :, None] + j8[None, None, :])   # (chunks, 4, 8)
+    dww = torch.cat([Wd10[unit].permute(0, 1, 3, 2), Wd10[hid + unit].permute(0, 1, 3, 2)], dim=-1)  # (chunks, 4, 10, 16)
+    W2p = torch.zeros(nt * 16, hid)
+    W2p[:C_] = W2
+    n_i = torch.arange(nt)[:, None] * 16 + n16[None, :]                                           # (nt, 64)
+    k_i = torch.arange(chunks)[:, None, None] * 32 + (8 * g4[:, None] + j8[None, :])[None]        # (chunks, 64, 8)
+    w2f = W2p[n_i[None, :, :, None].expand(chunks, nt, 64, 8), k_i[:, None].expand(chunks, nt, 64, 8)]
+    b2p = torch.zeros(nt * 16)
+    b2p[:C_] = b2
+    p = PackedFFN()
+    p.w1f = w1f.to(torch.bfloat16).contiguous().to(device)
+    p.w2f = w2f.to(torch.float16).contiguous().to(device)
+    p.dww = dww.to(torch.float16).contiguous().to(device)
+    p.b1, p.dwb, p.b2 = b1c.contiguous().to(device), bd.to(device), b2p.to(device)
+    p.chunks, p.C, p.hid, p.nt, p.ks, p.khalf = chunks, C_, hid, nt, ks, "v2"
+    return p
+
+
 def _ffn_desc(pf: PackedFFN, B, H, W, dtype):
     d = HatFfnDesc()
     d.B, d.H, d.W, d.C, d.chunks, d.dtype = B, H, W, pf.C, pf.chunks, dtype
@@ -403,6 +447,9 @@ def ffn(pf: PackedFFN, t_in, t_out, ln_g, ln_b, *, B: int, H: int, W: int, dtype
     # (with m_in, LayerNorm2(t_in) arrives pre-computed as T rows: it replaces the haloed fp32 read; t_in is still read
     # once for the residual)
     nbytes = B * H * W * (4.0 * pf.C + 4.0 * pf.C + (es * ldn if ln1 is not None else 0) + (es * ldm_in if m_in is not None else 0))
+    if pf.khalf == "v2":
+        _timed("ffn2_kernel", flops, lambda: _lib.check(lib.hat_ffn2(C.byref(d), _stream()), "hat_ffn2"), nbytes=nbytes)
+        return
     _timed(f"ffn_kernel<{_TNAME[dtype]}>", flops, lambda: _lib.check(lib.hat_ffn(C.byref(d), _stream()), "hat_ffn"),
            nbytes=nbytes)
 

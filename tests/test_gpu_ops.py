@@ -345,6 +345,55 @@ def test_esc_weights_and_eca(dtype, pdim, ks):
 
 
 # ------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("geom", [(2, 40, 48), (1, 13, 21), (1, 8, 16), (1, 67, 50)], ids=["B2_40x48", "ragged_13x21", "one_tile", "ragged_67x50"])
+def test_fused_ffn2(geom):
+    """hat_ffn2 (embed_dim 144, bf16 storage; fp16 hidden tensor, packed-fp16 depthwise conv + gate, fp16 fc2 MFMA) against
+    the oracle's GatedDconvFFN restatement in fp64 (hat_arch.py:107-119,237): interior tiles, every kind of border tile
+    (the depthwise conv zero-pads u AFTER the fc1 bias), ragged sizes, the fused next LayerNorm and its GAP partials."""
+    C = 144
+    B, H, W = geom
+    dev, ops = _dev(), _ops()
+    dt = ops.DTYPE_CODE["bf16"]
+    hid = 2 * C
+    t = rnd("ft2", (B, H * W, C), std=1.5) + 0.3
+    sd = {
+        "n2.weight": 1 + rnd("fg", (C,), std=0.1), "n2.bias": rnd("fbb", (C,), std=0.1),
+        "m.fc1.weight": q(rnd("f1w", (2 * hid, C), std=C ** -0.5), "bf16"), "m.fc1.bias": rnd("f1b", (2 * hid,), std=0.1),
+        "m.dw.weight": rnd("fdw", (2 * hid, 1, 3, 3), std=1 / 3).half().float(), "m.dw.bias": rnd("fdb", (2 * hid,), std=0.1).half().float(),
+        "m.fc2.weight": rnd("f2w", (C, hid), std=hid ** -0.5).half().float(), "m.fc2.bias": rnd("f2b", (C,), std=0.1),
+        "n1.weight": 1 + rnd("fg1", (C,), std=0.1), "n1.bias": rnd("fb1", (C,), std=0.1),
+    }
+    sdd = {k: v.double() for k, v in sd.items()}
+    ref = t.double() + O.gated_dconv_ffn(O._ln(t.double(), sdd, "n2"), (H, W), sdd, "m")
+    ref_n = O._ln(ref, sdd, "n1")
+    assert ops.ffn2_supported(C, hid, dt)
+    pf = ops.pack_ffn2(sd["m.fc1.weight"], sd["m.fc1.bias"], sd["m.dw.weight"], sd["m.dw.bias"], sd["m.fc2.weight"],
+                       sd["m.fc2.bias"], dev)
+    tin = t.to(dev).contiguous()
+    tout = torch.full_like(tin, 123.0)
+    nout = torch.zeros(B, H * W, C, dtype=torch.bfloat16, device=dev)
+    tiles = ops.ffn_tiles(pf, H, W, dt)
+    gap = torch.zeros(B, tiles, 16, device=dev)
+    dv = lambda k: sd[k].to(dev).contiguous()
+    ops.ffn(pf, tin, tout, dv("n2.weight"), dv("n2.bias"), B=B, H=H, W=W, dtype=dt, ln1=(dv("n1.weight"), dv("n1.bias")),
+            n_out=nout, ldn=C, gap_out=gap, gap_c=16)
+    torch.cuda.synchronize()
+    assert torch.isfinite(tout).all()
+    upd, upd_ref = (tout.double().cpu() - t.double()), (ref - t.double())
+    rel = float((upd - upd_ref).norm() / upd_ref.norm())
+    assert rel <= 1.0e-2, f"hat_ffn2 update rel err {rel:.3e}"
+    # per-pixel: no pixel (border ones in particular) may be off by more than a few bf16 ulps of the update scale
+    worst = float((upd - upd_ref).abs().max() / upd_ref.abs().max())
+    assert worst <= 4e-2, f"hat_ffn2 worst element {worst:.3e} of the update's range"
+    check(nout.float(), ref_n, "bf16", "hat_ffn2 next-LN")
+    check(gap.sum(1) / (H * W), ref_n[:, :, :16].mean(1), "f32", "hat_ffn2 gap partials", f32_tol=2e-3)
+    tout2 = torch.zeros_like(tin)
+    ops.ffn(pf, tin, tout2, dv("n2.weight"), dv("n2.bias"), B=B, H=H, W=W, dtype=dt)
+    torch.cuda.synchronize()
+    assert torch.equal(tout, tout2)
+
+
+# ------------------------------------------------------------------------------------------------
 @pytest.mark.parametrize("dtype", DT)
 @pytest.mark.parametrize("geom", [(144, 2, 40, 48), (180, 1, 24, 32), (24, 1, 13, 21)], ids=["C144", "C180", "C24"])
 def test_fused_ffn(dtype, geom):
