@@ -152,10 +152,14 @@ def _check_big(y, g, dtype, what, prefix=""):
     assert abs(float(yd.mean()) - float(P("mean"))) <= tol, f"{what}: global mean"
     assert abs(float(yd.std()) - float(P("std"))) <= 2 * tol, f"{what}: global std"
     assert abs(float(yd.abs().sum()) - float(P("abs_sum"))) <= tol * y.numel(), f"{what}: global abs-sum"
-    # row / column sums: an error confined to a band of rows or columns cannot hide in the global mean
+    # row / column sums: an error confined to a band of rows or columns cannot hide in the global mean.  Tolerance for a
+    # sum of n elements = n x (the tolerance of the global mean) + a 6-sigma random walk of the per-element error the dtype
+    # is allowed (fp32 1e-5; bf16 0.01 = the 40 dB floor)
     rs, cs = yd.sum(dim=-1), yd.sum(dim=-2)
-    assert float((rs - torch.as_tensor(P("row_sums")).double()).abs().max()) <= tol * y.shape[-1] * (1 if dtype == "f32" else 0.25), f"{what}: row sums"
-    assert float((cs - torch.as_tensor(P("col_sums")).double()).abs().max()) <= tol * y.shape[-2] * (1 if dtype == "f32" else 0.25), f"{what}: column sums"
+    sig = 1e-5 if dtype == "f32" else 1e-2
+    lim = lambda n: tol * n + 6.0 * sig * n ** 0.5
+    assert float((rs - torch.as_tensor(P("row_sums")).double()).abs().max()) <= lim(y.shape[-1]), f"{what}: row sums"
+    assert float((cs - torch.as_tensor(P("col_sums")).double()).abs().max()) <= lim(y.shape[-2]), f"{what}: column sums"
 
 
 @pytest.mark.parametrize("dtype", ["f32", "bf16"])
