@@ -313,6 +313,28 @@ int hat_ffn(const HatFfnDesc* d, void* stream);
  */
 int hat_ffn2(const HatFfnDesc* d, void* stream);
 
+/*
+ * The whole second half of a HAB (hat_arch.py:233-237 with esc_arch.py:123) in ONE kernel, embed_dim 144 / bf16:
+ *     tB    = t + W_aggr . [y16 | n[16:]] + wf . im2col3x3(c1) + bias_b        (= hat_aggr_cab, kept in registers / LDS)
+ *     t_out = tB + fc2( a * SiLU(g) ),  [a | g] = dwconv3x3( fc1( LayerNorm2(tB) ) )   (= hat_ffn2)
+ * `ffn` as for hat_ffn2 except that ffn.t_in is the residual stream BEFORE the aggregation (t); the fp32 tB that
+ * hat_aggr_cab would write and hat_ffn2 read back (with its halo) never exists in memory: 1 152 of the pair's 2 896
+ * algorithmic bytes per pixel.  The aggregation is evaluated on the haloed tile (10 x 18 pixels for 8 x 16 outputs).
+ * n: (B,H,W,ldn_in) T = LayerNorm1(t) whose first 16 channels are replaced by y16 (B,H,W,16) T; c1 (B,H,W,8) T;
+ * w_aggr: the aggregation weights fragment packed as for hat_linear (nt = 9, K = 160); wf, bias_b: hat_cab_fold's outputs.
+ */
+typedef struct HatHabTailDesc {
+    HatFfnDesc ffn;
+    const void* n;
+    const void* y16;
+    const void* c1;
+    const void* w_aggr;
+    const void* wf;
+    const float* bias_b;
+    int32_t ldn_in;
+} HatHabTailDesc;
+int hat_hab_tail(const HatHabTailDesc* d, void* stream);
+
 int hat_abi_version(void);
 /* name of the architecture the code objects in this library were compiled for ("gfx950") */
 const char* hat_target_arch(void);

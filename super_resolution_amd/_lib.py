@@ -57,6 +57,12 @@ class HatFfnDesc(C.Structure):
     ]
 
 
+class HatHabTailDesc(C.Structure):
+    """Mirror of `struct HatHabTailDesc` (include/hat_mi355x.h)."""
+    _fields_ = [("ffn", HatFfnDesc), ("n", C.c_void_p), ("y16", C.c_void_p), ("c1", C.c_void_p), ("w_aggr", C.c_void_p),
+                ("wf", C.c_void_p), ("bias_b", C.c_void_p), ("ldn_in", C.c_int32)]
+
+
 class HatCabFoldDesc(C.Structure):
     """Mirror of `struct HatCabFoldDesc` (include/hat_mi355x.h)."""
     _fields_ = [
@@ -89,6 +95,7 @@ SIGNATURES = {
     "hat_ffn_tiles": (C.c_int, [C.POINTER(HatFfnDesc), C.POINTER(C.c_int32)]),
     "hat_ffn": (C.c_int, [C.POINTER(HatFfnDesc), C.c_void_p]),
     "hat_ffn2": (C.c_int, [C.POINTER(HatFfnDesc), C.c_void_p]),
+    "hat_hab_tail": (C.c_int, [C.POINTER(HatHabTailDesc), C.c_void_p]),
     "hat_layernorm_blocks": (C.c_int, []),
     "hat_layernorm": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int64,
                                 C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_void_p]),

@@ -54,11 +54,25 @@ __device__ __forceinline__ u32x4 lds_read16(unsigned addr) { return *(__attribut
 __device__ __forceinline__ h2 as_h2(unsigned v) { return __builtin_bit_cast(h2, v); }
 __device__ __forceinline__ unsigned as_u(h2 v) { return __builtin_bit_cast(unsigned, v); }
 
+// Inputs of the fused aggregation stage (hat_hab_tail): stage 0 then computes tB = t + W_aggr . [y16 | n[16:]] +
+// wf . im2col3x3(c1) + bias_b itself (what hat_aggr_cab writes to HBM as fp32 and hat_ffn reads back with a halo) and
+// t_in is the residual stream BEFORE the aggregation.
+struct F2Aggr {
+    const bf16_t* n;       // (B,H,W,ldn) LayerNorm1 output
+    const bf16_t* y16;     // (B,H,W,16)  ESC large-kernel conv output: replaces channels [0, 16) of n
+    const bf16_t* c1;      // (B,H,W,8)   CAB squeeze conv output
+    const char* wl;        // aggregation weights, fragment packed [9][5][64][8] bf16
+    const char* wf;        // per-sample folded CAB expand weights [B][9][3][64][8] bf16 (hat_cab_fold)
+    const float* bias_b;   // per-sample bias [B][144]
+    int ldn;
+};
+__device__ __attribute__((aligned(16))) unsigned hat_ffn2_zero_page[4] = {0, 0, 0, 0};
+
 // DBG: timing-ablation mask for tools/ubench_ffn2.hip (the library instantiates 0):
 //   1 skip LN stage, 2 skip fc1 MFMAs, 4 skip the depthwise FMAs, 8 skip gate math, 16 skip fc2 MFMAs, 32 skip weight loads,
 //   64 per-phase s_memtime totals of every wave -> gap_out[wg][wave][8]
-template <int DBG>
-__global__ __launch_bounds__(256, 2) void ffn2_kernel(const HatFfnDesc d) {
+template <int DBG, bool AGGR = false>
+__global__ __launch_bounds__(256, 2) void ffn2_kernel(const HatFfnDesc d, const F2Aggr ag) {
     constexpr int C = F2_C, NT = F2_NT, KS = F2_KS, NTHR = 256, NPH = F2_NPH, HALO_W = F2_HW;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const unsigned lds0 = (unsigned)(uintptr_t)(lds_char*)smem;
@@ -86,76 +100,191 @@ __global__ __launch_bounds__(256, 2) void ffn2_kernel(const HatFfnDesc d) {
 
     // ------------------------------ stage 0: LayerNorm2 of the haloed tile -> Ms (bf16) --------------------------------
     // All global loads unconditional (clamped address, result discarded by a select) and issued before the first use.
-    if constexpr (!(DBG & 1)) {
-        const int j = tid & 15, grp = tid >> 4;
-        constexpr int NGRP = NTHR / 16, LNB = (NPH + NGRP - 1) / NGRP;   // 12 pixels per 16-lane group, one pass
-        const float invC = 1.0f / (float)C;
-        f32x4 gmv[3], btv[3];
+    f32x4 acc2[NT][2];   // persistent fc2 accumulators: this wave's two tile rows x 9 channel tiles
+    if constexpr (AGGR && !(DBG & 1)) {
+        // ---------------- stage 0, fused: aggregation + folded CAB + both residual terms + LayerNorm2 -> Ms ----------------
+        // All 80 KiB of LDS are free here, so the 72 KiB of A operands (9 n-tiles x 8 k-steps: 5 of the 144-wide aggregation,
+        // 3 of the 72-deep im2col of c1) are copied in ONCE per workgroup by LDS-DMA (fragment-contiguous: 1 KiB per wave
+        // instruction, no registers) and every wave multiplies three 16-pixel tiles against them: its own two tile rows —
+        // whose fp32 results stay in registers as the initial value of the fc2 accumulators (tB never exists in memory) — and
+        // one of the four halo tiles (top row, bottom row, left/right columns of rows 0-7, of rows 8-9).
+        {
+            const char* wfb = ag.wf + (size_t)b * NT * 3 * 1024;
 #pragma unroll
-        for (int v = 0; v < 3; ++v) {
-            const int c = min(4 * j + 64 * v, C - 4);
-            gmv[v] = *reinterpret_cast<const f32x4*>(d.ln_g + c);
-            btv[v] = *reinterpret_cast<const f32x4*>(d.ln_b + c);
+            for (int j = 0; j < 18; ++j) {
+                const int f = wave * 18 + j, nt = f >> 3, ks = f & 7;
+                const char* src = (ks < 5 ? ag.wl + (size_t)(nt * 5 + ks) * 1024 : wfb + (size_t)(nt * 3 + ks - 5) * 1024) + lane * 16;
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                                 (__attribute__((address_space(3))) void*)(smem + f * 1024), 16, 0, 0);
+            }
         }
-        f32x4 xv[LNB][3];
-        bool inside[LNB];
+        int hp[3], pix[3];
+        bool ins[3];
+        bf8 bfr[3][8];
+        const bf16_t* nb = ag.n + (size_t)b * H * W * ag.ldn;
+        const bf16_t* yb = ag.y16 + (size_t)b * H * W * 16;
+        const bf16_t* cb = ag.c1 + (size_t)b * H * W * 8;
 #pragma unroll
-        for (int u = 0; u < LNB; ++u) {
-            const int hp = u * NGRP + grp;
-            const int hy = hp / HALO_W, hx = hp - hy * HALO_W;
+        for (int t = 0; t < 3; ++t) {
+            int hy, hx;
+            if (t < 2) { hy = 2 * wave + 1 + t; hx = 1 + c16; }
+            else if (wave < 2) { hy = wave * (F2_ROWS + 1); hx = 1 + c16; }
+            else { const int jj = wave == 2 ? c16 : (c16 & 3); hy = (wave == 2 ? 0 : 8) + (jj >> 1); hx = (jj & 1) * (HALO_W - 1); }
             const int y = y0 - 1 + hy, x = x0 - 1 + hx;
-            inside[u] = hp < NPH && y >= 0 && y < H && x >= 0 && x < W;
-            const float* src = tin + ((size_t)min(max(y, 0), H - 1) * W + min(max(x, 0), W - 1)) * C;
+            ins[t] = y >= 0 && y < H && x >= 0 && x < W;
+            const int yc = min(max(y, 0), H - 1), xc = min(max(x, 0), W - 1);
+            hp[t] = hy * HALO_W + hx;
+            pix[t] = yc * W + xc;
 #pragma unroll
-            for (int v = 0; v < 3; ++v) xv[u][v] = *reinterpret_cast<const f32x4*>(src + min(4 * j + 64 * v, C - 4));
+            for (int ks = 0; ks < 5; ++ks) {
+                const int c = ks * 32 + 8 * g;
+                const bf16_t* src = c < 16 ? yb + (size_t)pix[t] * 16 + c : nb + (size_t)pix[t] * ag.ldn + min(c, C - 8);
+                bfr[t][ks] = MT<bf16_t>::load(src);
+            }
+#pragma unroll
+            for (int kc = 0; kc < 3; ++kc) {
+                const int tap = 4 * kc + g;
+                const int dy = tap / 3 - 1, dx = tap - (tap / 3) * 3 - 1;
+                const int yy = yc + dy, xx = xc + dx;
+                const bool inb = tap < 9 && yy >= 0 && yy < H && xx >= 0 && xx < W;
+                bfr[t][5 + kc] = MT<bf16_t>::load(inb ? cb + ((size_t)yy * W + xx) * 8 : reinterpret_cast<const bf16_t*>(hat_ffn2_zero_page));
+            }
         }
+        // The accumulators START as residual + bias (t and the per-sample bias, loaded straight into them in the MFMA D
+        // layout): the loads fly during the weight copy, cost no registers beyond the accumulators themselves and there is
+        // no residual pass after the GEMM.
+        f32x4 accx[NT];
+        {
+            const float* bbp = ag.bias_b + (size_t)b * NT * 16;
 #pragma unroll
-        for (int u = 0; u < LNB; ++u) {
-            const int hp = u * NGRP + grp;
-            // lanes j >= 4 of the third vector loaded channels 140..143 again (clamped address): they take no part in the
-            // statistics but normalise and store the same values to the same place as lane 3 — no branch, no lane mask
-            const f32x4 x2raw = xv[u][2];
+            for (int nt = 0; nt < NT; ++nt) {
+                const f32x4 bb = *reinterpret_cast<const f32x4*>(bbp + nt * 16 + 4 * g);
+                acc2[nt][0] = *reinterpret_cast<const f32x4*>(tin + (size_t)pix[0] * C + nt * 16 + 4 * g) + bb;
+                acc2[nt][1] = *reinterpret_cast<const f32x4*>(tin + (size_t)pix[1] * C + nt * 16 + 4 * g) + bb;
+                accx[nt] = *reinterpret_cast<const f32x4*>(tin + (size_t)pix[2] * C + nt * 16 + 4 * g) + bb;
+            }
+        }
+        __syncthreads();   // (drains vmcnt: the LDS-DMA copies of every wave have landed)
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) {
+#pragma unroll
+            for (int ks = 0; ks < 8; ++ks) {
+                const bf8 a = __builtin_bit_cast(bf8, lds_read16(lds0 + (unsigned)((nt * 8 + ks) * 1024) + (unsigned)lane * 16u));
+                acc2[nt][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, bfr[0][ks], acc2[nt][0], 0, 0, 0);
+                acc2[nt][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, bfr[1][ks], acc2[nt][1], 0, 0, 0);
+                accx[nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, bfr[2][ks], accx[nt], 0, 0, 0);
+            }
+        }
+        // LayerNorm2 parameters: requested now, in flight across the barrier
+        f32x4 gmv[NT], btv[NT];
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) {
+            gmv[nt] = *reinterpret_cast<const f32x4*>(d.ln_g + nt * 16 + 4 * g);
+            btv[nt] = *reinterpret_cast<const f32x4*>(d.ln_b + nt * 16 + 4 * g);
+        }
+        __syncthreads();   // every wave is done with the weights: Ms may be written
+        // LayerNorm2 (fp32 statistics over the 4 lane groups of a pixel) -> bf16 rows of Ms
+#pragma unroll
+        for (int t = 0; t < 3; ++t) {
+            f32x4 v[NT];
             float s = 0.f;
 #pragma unroll
-            for (int v = 0; v < 3; ++v) {
-                if (4 * j + 64 * v >= C) xv[u][v] = f32x4{0.f, 0.f, 0.f, 0.f};
-                s += (xv[u][v][0] + xv[u][v][1]) + (xv[u][v][2] + xv[u][v][3]);
+            for (int nt = 0; nt < NT; ++nt) {
+                v[nt] = t == 0 ? acc2[nt][0] : (t == 1 ? acc2[nt][1] : accx[nt]);
+                s += (v[nt][0] + v[nt][1]) + (v[nt][2] + v[nt][3]);
             }
-            s = row_sum16(s);
-            const float mean = s * invC;
+            s += __shfl_xor(s, 16); s += __shfl_xor(s, 32);
+            const float mean = s * (1.0f / (float)C);
             float q = 0.f;
 #pragma unroll
-            for (int v = 0; v < 3; ++v) {
+            for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
-                for (int r = 0; r < 4; ++r) { const float dl = xv[u][v][r] - mean; q += (4 * j + 64 * v < C) ? dl * dl : 0.f; }
+                for (int r = 0; r < 4; ++r) { const float dl = v[nt][r] - mean; q += dl * dl; }
+            q += __shfl_xor(q, 16); q += __shfl_xor(q, 32);
+            const float rstd = __builtin_amdgcn_rsqf(q * (1.0f / (float)C) + 1e-5f);
+            char* rowp = smem + hp[t] * F2_MS_ROWB + 8 * g;
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) {
+                f32x4 o;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) o[r] = ins[t] ? (v[nt][r] - mean) * rstd * gmv[nt][r] + btv[nt][r] : 0.f;
+                Vec4<bf16_t>::store(reinterpret_cast<bf16_t*>(rowp + nt * 32), o);
+                // the wave's own rows: tB + fc2 bias is where the fc2 accumulation starts
+                if (t < 2) acc2[nt][t] = v[nt] + *reinterpret_cast<const f32x4*>(d.b2 + nt * 16 + 4 * g);
             }
-            q = row_sum16(q);
-            const float rstd = __builtin_amdgcn_rsqf(q * invC + 1e-5f);
-            // pixels past the end of the haloed tile (the last pass is partial) store into a scratch line instead
-            char* rowp = smem + (hp < NPH ? hp * F2_MS_ROWB : F2_RED_OFF);
+        }
+    } else {
+        if constexpr (!(DBG & 1)) {
+            const int j = tid & 15, grp = tid >> 4;
+            constexpr int NGRP = NTHR / 16, LNB = (NPH + NGRP - 1) / NGRP;   // 12 pixels per 16-lane group, one pass
+            const float invC = 1.0f / (float)C;
+            f32x4 gmv[3], btv[3];
 #pragma unroll
             for (int v = 0; v < 3; ++v) {
                 const int c = min(4 * j + 64 * v, C - 4);
-                const f32x4 xs = v == 2 ? x2raw : xv[u][v];
-                f32x4 o;
+                gmv[v] = *reinterpret_cast<const f32x4*>(d.ln_g + c);
+                btv[v] = *reinterpret_cast<const f32x4*>(d.ln_b + c);
+            }
+            f32x4 xv[LNB][3];
+            bool inside[LNB];
 #pragma unroll
-                for (int r = 0; r < 4; ++r) o[r] = inside[u] ? (xs[r] - mean) * rstd * gmv[v][r] + btv[v][r] : 0.f;
-                Vec4<bf16_t>::store(reinterpret_cast<bf16_t*>(rowp) + c, o);
+            for (int u = 0; u < LNB; ++u) {
+                const int hp = u * NGRP + grp;
+                const int hy = hp / HALO_W, hx = hp - hy * HALO_W;
+                const int y = y0 - 1 + hy, x = x0 - 1 + hx;
+                inside[u] = hp < NPH && y >= 0 && y < H && x >= 0 && x < W;
+                const float* src = tin + ((size_t)min(max(y, 0), H - 1) * W + min(max(x, 0), W - 1)) * C;
+#pragma unroll
+                for (int v = 0; v < 3; ++v) xv[u][v] = *reinterpret_cast<const f32x4*>(src + min(4 * j + 64 * v, C - 4));
+            }
+#pragma unroll
+            for (int u = 0; u < LNB; ++u) {
+                const int hp = u * NGRP + grp;
+                // lanes j >= 4 of the third vector loaded channels 140..143 again (clamped address): they take no part in the
+                // statistics but normalise and store the same values to the same place as lane 3 — no branch, no lane mask
+                const f32x4 x2raw = xv[u][2];
+                float s = 0.f;
+#pragma unroll
+                for (int v = 0; v < 3; ++v) {
+                    if (4 * j + 64 * v >= C) xv[u][v] = f32x4{0.f, 0.f, 0.f, 0.f};
+                    s += (xv[u][v][0] + xv[u][v][1]) + (xv[u][v][2] + xv[u][v][3]);
+                }
+                s = row_sum16(s);
+                const float mean = s * invC;
+                float q = 0.f;
+#pragma unroll
+                for (int v = 0; v < 3; ++v) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) { const float dl = xv[u][v][r] - mean; q += (4 * j + 64 * v < C) ? dl * dl : 0.f; }
+                }
+                q = row_sum16(q);
+                const float rstd = __builtin_amdgcn_rsqf(q * invC + 1e-5f);
+                // pixels past the end of the haloed tile (the last pass is partial) store into a scratch line instead
+                char* rowp = smem + (hp < NPH ? hp * F2_MS_ROWB : F2_RED_OFF);
+#pragma unroll
+                for (int v = 0; v < 3; ++v) {
+                    const int c = min(4 * j + 64 * v, C - 4);
+                    const f32x4 xs = v == 2 ? x2raw : xv[u][v];
+                    f32x4 o;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) o[r] = inside[u] ? (xs[r] - mean) * rstd * gmv[v][r] + btv[v][r] : 0.f;
+                    Vec4<bf16_t>::store(reinterpret_cast<bf16_t*>(rowp) + c, o);
+                }
             }
         }
-    }
 
-    __builtin_amdgcn_sched_barrier(0);   // (stage 0 is one basic block: keep the loads below out of its 144 live registers)
-    // persistent fc2 accumulators: this wave's two tile rows x 9 channel tiles, initialised with t_in + b2
-    f32x4 acc2[NT][2];
+        __builtin_amdgcn_sched_barrier(0);   // (stage 0 is one basic block: keep the loads below out of its 144 live registers)
+        // fc2 accumulators initialised with t_in + b2
 #pragma unroll
-    for (int pt = 0; pt < 2; ++pt) {
-        const size_t pixc = (size_t)min(y0 + 2 * wave + pt, H - 1) * W + min(x0 + c16, W - 1);
+        for (int pt = 0; pt < 2; ++pt) {
+            const size_t pixc = (size_t)min(y0 + 2 * wave + pt, H - 1) * W + min(x0 + c16, W - 1);
 #pragma unroll
-        for (int nt = 0; nt < NT; ++nt) {
-            const int n = nt * 16 + 4 * g;
-            acc2[nt][pt] = *reinterpret_cast<const f32x4*>(d.b2 + n) + *reinterpret_cast<const f32x4*>(tin + pixc * C + n);
+            for (int nt = 0; nt < NT; ++nt) {
+                const int n = nt * 16 + 4 * g;
+                acc2[nt][pt] = *reinterpret_cast<const f32x4*>(d.b2 + n) + *reinterpret_cast<const f32x4*>(tin + pixc * C + n);
+            }
         }
+
     }
 
     const bf16_t* w1f = reinterpret_cast<const bf16_t*>(d.w1f);
@@ -439,18 +568,37 @@ __global__ __launch_bounds__(256, 2) void ffn2_kernel(const HatFfnDesc d) {
 }  // namespace
 
 #ifndef HAT_FFN2_NO_ENTRY
-extern "C" int hat_ffn2(const HatFfnDesc* dp, void* stream) {
-    if (!dp) return HAT_EINVAL;
-    const HatFfnDesc& d = *dp;
+namespace {
+int ffn2_check(const HatFfnDesc& d) {
     if (!d.t_in || !d.t_out || d.t_in == d.t_out || !d.ln_g || !d.ln_b || !d.w1f || !d.b1 || !d.dww || !d.w2f || !d.b2) return HAT_EINVAL;
     if (d.B < 1 || d.H < 1 || d.W < 1 || d.chunks < 1 || d.m_in) return HAT_EINVAL;
     if (d.C != F2_C || d.dtype != HAT_BF16) return HAT_EUNSUPPORTED;
     if (d.ln1_g && (!d.ln1_b || !d.n_out || d.ldn < d.C || d.ldn % 4 || d.gap_c < 0 || d.gap_c > 16 || d.gap_c % 4)) return HAT_EINVAL;
-    auto kern = ffn2_kernel<0>;
+    return 0;
+}
+template <bool AGGR> int ffn2_launch(const HatFfnDesc& d, const F2Aggr& ag, void* stream) {
+    auto kern = ffn2_kernel<0, AGGR>;
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, F2_LDS);
     if (e != hipSuccess) return (int)e;
     dim3 grid((d.W + 15) / 16, (d.H + F2_ROWS - 1) / F2_ROWS, d.B);
-    HAT_LAUNCH(kern, grid, dim3(256), F2_LDS, reinterpret_cast<hipStream_t>(stream), d);
+    HAT_LAUNCH(kern, grid, dim3(256), F2_LDS, reinterpret_cast<hipStream_t>(stream), d, ag);
     return hat_check_launch();
+}
+}  // namespace
+
+extern "C" int hat_ffn2(const HatFfnDesc* dp, void* stream) {
+    if (!dp) return HAT_EINVAL;
+    if (int rc = ffn2_check(*dp)) return rc;
+    return ffn2_launch<false>(*dp, F2Aggr{}, stream);
+}
+
+extern "C" int hat_hab_tail(const HatHabTailDesc* dp, void* stream) {
+    if (!dp) return HAT_EINVAL;
+    const HatHabTailDesc& h = *dp;
+    if (int rc = ffn2_check(h.ffn)) return rc;
+    if (!h.n || !h.y16 || !h.c1 || !h.w_aggr || !h.wf || !h.bias_b || h.ldn_in < F2_C || h.ldn_in % 8) return HAT_EINVAL;
+    const F2Aggr ag{reinterpret_cast<const bf16_t*>(h.n), reinterpret_cast<const bf16_t*>(h.y16), reinterpret_cast<const bf16_t*>(h.c1),
+                    reinterpret_cast<const char*>(h.w_aggr), reinterpret_cast<const char*>(h.wf), h.bias_b, h.ldn_in};
+    return ffn2_launch<true>(h.ffn, ag, stream);
 }
 #endif

@@ -166,6 +166,8 @@ class HATEngine:
                         hb["ffn"] = ops.pack_ffn2(*fw, dev)
                     else:
                         hb["ffn"] = ops.pack_ffn(*fw, dt, dev)
+                    hb["tail"] = ("fold" in hb and hb["esc"].pdim == 16 and ops.hab_tail_supported(hb["ffn"], hb["esc"].aggr, w2raw.shape[1], dt)
+                                  and os.environ.get("HAT_NO_HAB_TAIL") != "1")
                 L["habs"].append(hb)
             p = f"layers.{g}.residual_group.overlap_attn"
             d = C // heads
@@ -231,7 +233,7 @@ class HATEngine:
         f = torch.float32
         w = {
             "f0": z(B, N, C, dtype=f), "tA": z(B, N, C, dtype=f), "tB": z(B, N, C, dtype=f), "tC": z(B, N, C, dtype=f),
-            "n": z(B, N, _r8(C)), "c1": z(B, N, _r8(mid)), "c2": z(B, N, _r8(C)), "m2": z(B, N, ops.ffn_m_ld(C)),
+            "n": z(B, N, _r8(C)), "n2b": z(B, N, _r8(C)), "c1": z(B, N, _r8(mid)), "c2": z(B, N, _r8(C)), "m2": z(B, N, ops.ffn_m_ld(C)),
             "y16": z(B, N, 16), "u": z(B, N, _r8(max(hid2, 2 * C))), "g": z(B, N, _r8(max(hid2 // 2, 2 * C))),
             "q": z(B, N, _r8(C)), "kv": z(B, N, _r8(2 * C)), "ao": z(B, N, _r8(C)),
             "fb": z(B, N, 64),
@@ -313,7 +315,7 @@ class HATEngine:
         x = x.to(torch.float32).contiguous()
         cfg, dt, C = self.cfg, self.dtype, self.C
         N, ldc = H * W, _r8(C)
-        w = self._workspace(B, H, W)
+        w = dict(self._workspace(B, H, W))   # (a shallow copy: the forward swaps the two LayerNorm-output buffers locally)
         s = self.scale
         y = torch.empty(B, cfg["in_chans"], H * s, W * s, dtype=torch.float32, device=self.dev)
         mean = RGB_MEAN if cfg["in_chans"] == 3 else (0.0,) * 4
@@ -371,6 +373,19 @@ class HATEngine:
                                  hb["eca_w"].numel(), fo["ba"], float(cfg["conv_scale"]), w["scale"], w["wf"], w["bias_b"],
                                  w["eca_tmp"], B=B, H=H, W=W, C_=C, mid=mid, dtype=dt)
                     s0.wait_stream(s1)                              # y16 is ready
+                    if hb.get("tail"):
+                        # aggregation + folded CAB + residuals + the whole FFN in ONE launch: tB never exists in HBM
+                        if i + 1 < len(L["habs"]):
+                            nxt, gap_c = L["habs"][i + 1]["n1"], L["habs"][i + 1]["esc"].pdim
+                        else:
+                            nxt, gap_c = oc["n1"], (oc["esc"].pdim if "esc" in oc else 0)
+                        tout = tB if t is not tB else tC
+                        ops.hab_tail(hb["ffn"], esc.aggr, t, tout, hb["n2"][0], hb["n2"][1], n=w["n"], ldn_in=ldc, y16=w["y16"],
+                                     c1=w["c1"], wf=w["wf"], bias_b=w["bias_b"], B=B, H=H, W=W, dtype=dt, ln1=nxt, n_out=w["n2b"],
+                                     ldn=ldc, gap_out=w["gap"], gap_c=gap_c)
+                        w["n"], w["n2b"] = w["n2b"], w["n"]      # the kernel reads n with a halo: its output n' is another buffer
+                        t, have_n, nblk = tout, True, ops.ffn_tiles(hb["ffn"], H, W, dt)
+                        continue
                     ops.aggr_cab(esc.aggr, w["n"], tB, w["c1"], w["wf"], w["bias_b"], **geo, ldx=ldc, ldo=C, x0=w["y16"],
                                  c_split=esc.pdim, ldx0=16, r1=t, ldr1=C)
                     pre_ln = False

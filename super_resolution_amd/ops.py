@@ -11,7 +11,7 @@ import torch
 
 from . import _lib
 from ._lib import (ACT_GELU, ACT_LRELU, ACT_NONE, HAT_BF16, HAT_F32, O_NCHW_F32, O_NHWC_F32, O_NHWC_T, O_PIXSHUF_T,
-                   X_NCHW_F32_MEAN, X_NHWC_F32, X_NHWC_T, HatAggrCabDesc, HatCabFoldDesc, HatConvDesc, HatFfnDesc)
+                   X_NCHW_F32_MEAN, X_NHWC_F32, X_NHWC_T, HatAggrCabDesc, HatCabFoldDesc, HatConvDesc, HatFfnDesc, HatHabTailDesc)
 
 TORCH_DTYPE = {HAT_F32: torch.float32, HAT_BF16: torch.bfloat16}
 DTYPE_CODE = {"f32": HAT_F32, "fp32": HAT_F32, "float32": HAT_F32, "bf16": HAT_BF16, "bfloat16": HAT_BF16}
@@ -429,10 +429,7 @@ def ffn_m_ld(C_: int) -> int:
     return (C_ + 1 + 31) // 32 * 32
 
 
-def ffn(pf: PackedFFN, t_in, t_out, ln_g, ln_b, *, B: int, H: int, W: int, dtype: int, ln1=None, n_out=None, ldn: int = 0,
-        gap_out=None, gap_c: int = 0, m_in=None, ldm_in: int = 0):
-    lib = _lib.load()
-    d = _ffn_desc(pf, B, H, W, dtype)
+def _fill_ffn(d, pf: PackedFFN, t_in, t_out, ln_g, ln_b, ln1, n_out, ldn, gap_out, gap_c, m_in=None, ldm_in=0):
     d.t_in, d.t_out, d.ln_g, d.ln_b = _ptr(t_in), _ptr(t_out), _ptr(ln_g), _ptr(ln_b)
     if m_in is not None:
         d.m_in, d.ldm_in = _ptr(m_in), ldm_in
@@ -440,6 +437,13 @@ def ffn(pf: PackedFFN, t_in, t_out, ln_g, ln_b, *, B: int, H: int, W: int, dtype
     if ln1 is not None:
         d.ln1_g, d.ln1_b, d.n_out, d.ldn = _ptr(ln1[0]), _ptr(ln1[1]), _ptr(n_out), ldn
         d.gap_out, d.gap_c = (_ptr(gap_out) if gap_c else None), gap_c
+
+
+def ffn(pf: PackedFFN, t_in, t_out, ln_g, ln_b, *, B: int, H: int, W: int, dtype: int, ln1=None, n_out=None, ldn: int = 0,
+        gap_out=None, gap_c: int = 0, m_in=None, ldm_in: int = 0):
+    lib = _lib.load()
+    d = _ffn_desc(pf, B, H, W, dtype)
+    _fill_ffn(d, pf, t_in, t_out, ln_g, ln_b, ln1, n_out, ldn, gap_out, gap_c, m_in, ldm_in)
     flops = B * H * W * (2.0 * pf.C * 2 * pf.hid + 2.0 * 9 * 2 * pf.hid + 2.0 * pf.hid * pf.C)
     # algorithmic HBM bytes per pixel: t_in read once (fp32), t_out written (fp32), the next block's LayerNorm output
     # written (T); weights and the on-chip hidden tensor do not count
@@ -452,6 +456,27 @@ def ffn(pf: PackedFFN, t_in, t_out, ln_g, ln_b, *, B: int, H: int, W: int, dtype
         return
     _timed(f"ffn_kernel<{_TNAME[dtype]}>", flops, lambda: _lib.check(lib.hat_ffn(C.byref(d), _stream()), "hat_ffn"),
            nbytes=nbytes)
+
+
+def hab_tail_supported(pf: PackedFFN, aggr: PackedConv, mid: int, dtype: int) -> bool:
+    return pf.khalf == "v2" and aggr.frag and aggr.nt == 9 and aggr.n_slices == 1 and aggr.kpad == 160 and mid <= 8 and dtype == HAT_BF16
+
+
+def hab_tail(pf: PackedFFN, aggr: PackedConv, t_in, t_out, ln_g, ln_b, *, n, ldn_in: int, y16, c1, wf, bias_b, B: int, H: int,
+             W: int, dtype: int, ln1=None, n_out=None, ldn: int = 0, gap_out=None, gap_c: int = 0):
+    """hat_hab_tail: aggregation + folded CAB + residuals + the whole gated FFN in one launch (t_in = the residual stream
+    BEFORE the aggregation)."""
+    lib = _lib.load()
+    h = HatHabTailDesc()
+    d = h.ffn
+    d.B, d.H, d.W, d.C, d.chunks, d.dtype = B, H, W, pf.C, pf.chunks, dtype
+    _fill_ffn(d, pf, t_in, t_out, ln_g, ln_b, ln1, n_out, ldn, gap_out, gap_c)
+    h.n, h.y16, h.c1, h.w_aggr, h.wf, h.bias_b, h.ldn_in = _ptr(n), _ptr(y16), _ptr(c1), _ptr(aggr.w), _ptr(wf), _ptr(bias_b), ldn_in
+    flops = B * H * W * (2.0 * pf.C * (pf.C + 72) + 2.0 * pf.C * 2 * pf.hid + 2.0 * 9 * 2 * pf.hid + 2.0 * pf.hid * pf.C)
+    # algorithmic HBM bytes per pixel: n (T), y16 (T x 16), c1 (T x 8), t (fp32) read once; t_out (fp32) and the next
+    # block's LayerNorm output (T) written
+    nbytes = B * H * W * (2.0 * ldn_in + 32 + 16 + 4.0 * pf.C + 4.0 * pf.C + (2 * ldn if ln1 is not None else 0))
+    _timed("ffn2_kernel<aggr>", flops, lambda: _lib.check(lib.hat_hab_tail(C.byref(h), _stream()), "hat_hab_tail"), nbytes=nbytes)
 
 
 # ------------------------------------------------------------------------------------------------

@@ -597,6 +597,77 @@ def test_aggr_with_folded_cab(geom):
     check(out.reshape(B, H, W, C), ref, dtype, "aggr + folded cab")
 
 
+@pytest.mark.parametrize("geom", [(2, 24, 40), (1, 19, 27), (1, 8, 16), (1, 35, 64)], ids=["B2_24x40", "ragged_19x27", "one_tile", "35x64"])
+def test_hab_tail_fused(geom):
+    """hat_hab_tail = hat_aggr_cab + hat_ffn2 in one launch (hat_arch.py:233-237, esc_arch.py:123): t + aggr([y16 | n[16:]]) +
+    folded CAB, LayerNorm2, gated depthwise FFN, residual, next LayerNorm + GAP partials.  Checked against (a) the two-kernel
+    sequence it replaces (same arithmetic, tB merely never leaves the chip: agreement to a few flipped bf16 roundings) and (b) an
+    fp64 restatement, on interior and border tiles, ragged sizes and B = 2."""
+    B, H, W = geom
+    C, mid, hid = 144, 6, 288
+    dev, ops = _dev(), _ops()
+    dt = ops.DTYPE_CODE["bf16"]
+    tdt = torch.bfloat16
+    n = q(rnd("htn", (B, H, W, C)), "bf16")
+    y16 = q(rnd("hty", (B, H, W, 16)), "bf16")
+    c1 = q(F.gelu(rnd("htc1", (B, H, W, mid))), "bf16")
+    t = rnd("htt", (B, H, W, C), std=1.5) + 0.3
+    wa, ba = q(rnd("htwa", (C, C), std=C ** -0.5), "bf16"), rnd("htba", (C,), std=0.1)
+    w2, b2c = rnd("htw2", (C, mid, 3, 3), std=(9 * mid) ** -0.5), rnd("htb2", (C,), std=0.1)
+    wk = rnd("htwk", (5,), std=1.0)
+    conv_scale = 0.37
+    sd = {
+        "n2.weight": 1 + rnd("fg", (C,), std=0.1), "n2.bias": rnd("fbb", (C,), std=0.1),
+        "m.fc1.weight": q(rnd("f1w", (2 * hid, C), std=C ** -0.5), "bf16"), "m.fc1.bias": rnd("f1b", (2 * hid,), std=0.1),
+        "m.dw.weight": rnd("fdw", (2 * hid, 1, 3, 3), std=1 / 3).half().float(), "m.dw.bias": rnd("fdb", (2 * hid,), std=0.1).half().float(),
+        "m.fc2.weight": rnd("f2w", (C, hid), std=hid ** -0.5).half().float(), "m.fc2.bias": rnd("f2b", (C,), std=0.1),
+        "n1.weight": 1 + rnd("fg1", (C,), std=0.1), "n1.bias": rnd("fb1", (C,), std=0.1),
+    }
+    sdd = {k: v.double() for k, v in sd.items()}
+    # fp64 restatement
+    c2 = F.conv2d(c1.permute(0, 3, 1, 2).double(), w2.double(), b2c.double(), padding=1)
+    e = torch.sigmoid(F.conv1d(c2.mean((2, 3))[:, None, :], wk.double()[None, None, :], padding=2))[:, 0]
+    xin = torch.cat([y16, n[..., 16:]], -1)
+    tb = t.double() + F.linear(xin.double(), wa.double(), ba.double()) + conv_scale * (e[:, :, None, None] * c2).permute(0, 2, 3, 1)
+    tb = tb.reshape(B, H * W, C)
+    ref = tb + O.gated_dconv_ffn(O._ln(tb, sdd, "n2"), (H, W), sdd, "m")
+    ref_n = O._ln(ref, sdd, "n1")
+    # device: fold, then the two-kernel sequence and the fused kernel
+    pw = ops.pack_linear_weight(wa, ba, dt, dev)
+    pf = ops.pack_ffn2(sd["m.fc1.weight"], sd["m.fc1.bias"], sd["m.dw.weight"], sd["m.dw.bias"], sd["m.fc2.weight"], sd["m.fc2.bias"], dev)
+    assert ops.hab_tail_supported(pf, pw, mid, dt)
+    c1d = to_dev(c1, 8, tdt, dev)
+    colsum = torch.zeros(B, 1, 16, device=dev)
+    colsum[:, 0, :8] = c1d.float().sum(1)
+    scale = torch.zeros(B, pw.npad, device=dev)
+    wf = torch.zeros(B, pw.nt * 3 * 512, dtype=tdt, device=dev)
+    bias_b = torch.zeros(B, pw.npad, device=dev)
+    ops.cab_fold(c1d, colsum, 1, 16, w2.to(dev).contiguous(), b2c.to(dev), wk.to(dev), 5, ba.to(dev), conv_scale, scale, wf, bias_b,
+                 torch.zeros(B, 32, 16, device=dev), B=B, H=H, W=W, C_=C, mid=mid, dtype=dt)
+    nd, yd, td = to_dev(n, C, tdt, dev), to_dev(y16, 16, tdt, dev), t.reshape(B, H * W, C).to(dev).contiguous()
+    dv = lambda k: sd[k].to(dev).contiguous()
+    tiles = ops.ffn_tiles(pf, H, W, dt)
+    kw = dict(B=B, H=H, W=W, dtype=dt, ln1=(dv("n1.weight"), dv("n1.bias")), ldn=C, gap_c=16)
+    tB = torch.zeros(B, H * W, C, device=dev)
+    ops.aggr_cab(pw, nd, tB, c1d, wf, bias_b, B=B, H=H, W=W, dtype=dt, ldx=C, ldo=C, x0=yd, c_split=16, ldx0=16, r1=td, ldr1=C)
+    out2, n2, gap2 = torch.zeros_like(tB), torch.zeros(B, H * W, C, dtype=tdt, device=dev), torch.zeros(B, tiles, 16, device=dev)
+    ops.ffn(pf, tB, out2, dv("n2.weight"), dv("n2.bias"), n_out=n2, gap_out=gap2, **kw)
+    out1, n1, gap1 = torch.full_like(tB, 7.0), torch.zeros_like(n2), torch.zeros_like(gap2)
+    ops.hab_tail(pf, pw, td, out1, dv("n2.weight"), dv("n2.bias"), n=nd, ldn_in=C, y16=yd, c1=c1d, wf=wf, bias_b=bias_b,
+                 n_out=n1, gap_out=gap1, **kw)
+    torch.cuda.synchronize()
+    assert torch.isfinite(out1).all()
+    d12 = float((out1 - out2).abs().max())
+    # same arithmetic; fp32 round-off in tB may flip single bf16 roundings of LayerNorm2's output (an ulp is 0.4 %)
+    assert d12 <= 1e-3 * max(1.0, float(out2.abs().max())), f"fused vs two-kernel sequence: max-abs {d12:.3e}"
+    assert float((n1.float() - n2.float()).abs().max()) <= 0.04 and float((gap1 - gap2).abs().max()) <= 1e-2 * H * W / tiles
+    upd, upd_ref = out1.double().cpu() - tb, ref - tb
+    rel = float((upd - upd_ref).norm() / upd_ref.norm())
+    assert rel <= 1.2e-2, f"hab tail FFN update rel err {rel:.3e}"
+    check(out1, ref, "bf16", "hab tail t_out")
+    check(n1.float(), ref_n, "bf16", "hab tail next-LN")
+
+
 # ------------------------------------------------------------------------------------------------
 # (S)W-MSA branch (SURVEY §8 row f2): hat_linear -> hat_window_attention -> hat_linear
 # ------------------------------------------------------------------------------------------------
