@@ -249,7 +249,7 @@ def main():
             gbs = e[3] / e[0] / avg_s / 1e9
             roofline = {"bound": "hbm", "kernel": dom, "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                         "frac": round(gbs / HBM_PEAK_GBS, 4), "traffic": None,
-                        "bytes_per_launch": round(e[3] / e[0]), "bytes_unit": "algorithmic HBM bytes (DESIGN.md, hat_ffn)",
+                        "bytes_per_launch": round(e[3] / e[0]), "bytes_unit": "algorithmic HBM bytes per launch (DESIGN.md §5: operands read once, results written once)",
                         "mfma_tflops": round(tflops, 2), "mfma_frac": round(tflops / peak_tf, 4),
                         "intensity_flop_per_byte": round(e[2] / e[3], 1)}
         else:

@@ -373,7 +373,7 @@ class HATEngine:
                                  hb["eca_w"].numel(), fo["ba"], float(cfg["conv_scale"]), w["scale"], w["wf"], w["bias_b"],
                                  w["eca_tmp"], B=B, H=H, W=W, C_=C, mid=mid, dtype=dt)
                     s0.wait_stream(s1)                              # y16 is ready
-                    if hb.get("tail"):
+                    if hb.get("tail"):   # (also the faster choice on small frames: 64x64 HAT-S 3.97 vs 6.19 ms per forward)
                         # aggregation + folded CAB + residuals + the whole FFN in ONE launch: tB never exists in HBM
                         if i + 1 < len(L["habs"]):
                             nxt, gap_c = L["habs"][i + 1]["n1"], L["habs"][i + 1]["esc"].pdim

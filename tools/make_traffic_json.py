@@ -1,5 +1,5 @@
 """Turn the FETCH_SIZE / WRITE_SIZE passes (rocprofv3 --pmc, one counter per pass, tools/run_forward.py as the target)
-into profiles/r01_hbm_traffic.json: HBM bytes per launch of every hat kernel.
+into profiles/rNN_hbm_traffic.json: HBM bytes per launch of every hat kernel.
     python tools/make_traffic_json.py gpurun_out/pmcF gpurun_out/pmcW profiles/r01_hbm_traffic.json HAT-S 4 720 1280 bf16
 Corrections (MI355X_MICROARCH.md, HBM section): both counters are in KiB; on gfx950 FETCH_SIZE tallies the 128-byte
 requests of wide (16 B/lane) reads at 64 bytes, so it is doubled; WRITE_SIZE is exact for 16 B/lane streaming stores."""
@@ -7,6 +7,7 @@ import csv, glob, json, re, sys, collections
 
 fdir, wdir, out, model, scale, H, W, dtype = sys.argv[1:9]
 BENCH_NAME = [  # rocprof kernel-name pattern -> the name bench.py prints
+    (r"ffn2_kernelILi0ELb1E|ffn2_kernel<0, true", "ffn2_kernel<aggr>"), (r"ffn2_kernel", "ffn2_kernel"),
     (r"ffn_kernel", "ffn_kernel<__bf16>"), (r"ocab_attn", "ocab_attn_kernel<__bf16>"), (r"aggr_cab_kernel", "aggr_cab_kernel"),
     (r"pw_kernel.*ELi5E", "pw_kernel<__bf16, 9, 5>"), (r"pw_kernel.*ELi9E", "pw_kernel<__bf16, 9, 9>"),
     (r"cab_squeeze_kernel(ILi5E|<5)", "cab_squeeze_kernel"), (r"cab_squeeze_kernel(ILi2E|<2)", "cab_squeeze_kernel<2, planes>"),

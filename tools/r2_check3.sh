@@ -1,3 +1,5 @@
 #!/bin/bash
 set -o pipefail
-timeout -k 10 120 tools/bin/ubench_ffn2_w1 2>&1 | tee gpurun_out/r2_ub2w1_abl.log
+echo "== warm-up on"; timeout -k 10 120 tools/bin/ubench_ffn2 2>&1 | head -4
+echo "== warm-up off"; timeout -k 10 120 tools/bin/ubench_ffn2_nopf 2>&1 | head -4
+UB_PHASES=1 UB_AGGR=1 timeout -k 10 120 tools/bin/ubench_ffn2 2>&1 | head -4
