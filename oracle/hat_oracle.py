@@ -397,6 +397,184 @@ def blank_state_dict(cfg: dict) -> SD:
 
 
 # --------------------------------------------------------------------------------------------
+# HATX variant: hat/archs/hatx_arch.py — SGFN feed-forward in the HAB, OCAB with ceil padding,
+# focus bias and top-k key pruning.  Everything else (CAB, ESC, RHAG, head / tail) is the HAT path above.
+# --------------------------------------------------------------------------------------------
+HATX_DEFAULT_CFG = dict(DEFAULT_CFG, hab_ffn_ratio=2.0, kv_topk_ratio=1.0, use_focus_bias=False)  # hatx_arch.py:714-751
+
+
+def make_hatx_cfg(**kw) -> dict:
+    cfg = dict(HATX_DEFAULT_CFG)
+    for k, v in kw.items():
+        if k in cfg:
+            cfg[k] = v
+    return cfg
+
+
+def sgfn(m: Tensor, hw, sd: SD, p: str) -> Tensor:
+    """SpatialGateDConvFFN.forward, hatx_arch.py:160-180: fc1, depthwise 3x3 on the FIRST half only, the second half gates
+    (SiLU) and is also passed on: fc2(cat[dw(a) * silu(b), b])."""
+    u = F.linear(m, sd[p + ".fc1.weight"], sd[p + ".fc1.bias"])
+    c2 = u.shape[-1] // 2
+    xa = F.conv2d(_tok2img(u[..., :c2], hw), sd[p + ".dw.weight"], sd[p + ".dw.bias"], padding=1, groups=c2)
+    xb = u[..., c2:]
+    return F.linear(torch.cat([_img2tok(xa) * F.silu(xb), xb], dim=-1), sd[p + ".fc2.weight"], sd[p + ".fc2.bias"])
+
+
+def hatx_hab(t: Tensor, hw, sd: SD, p: str, cfg: dict) -> Tensor:
+    """HAB.forward of hatx_arch.py:232-257 (= hat_arch's with the SGFN)."""
+    n = _ln(t, sd, p + ".norm1")
+    n_img = _tok2img(n, hw)
+    conv_x = _img2tok(cab(n_img, sd, p + ".conv_block"))
+    attn_x = _img2tok(esc_conv_attn(n_img, sd[p + ".esc_attn.plk_filter"], sd, p + ".esc_attn.core", cfg["esc_pdim"]))
+    t = t + attn_x + conv_x * cfg["conv_scale"]
+    return t + sgfn(_ln(t, sd, p + ".norm2"), hw, sd, p + ".mlp")
+
+
+def hatx_ocab_attention(q: Tensor, k: Tensor, v: Tensor, table: Tensor, rpi: Tensor, ws: int, wse: int, heads: int, scale: float,
+                        sal: Optional[Tensor] = None, topk_ratio: float = 1.0) -> Tensor:
+    """Attention core of hatx_arch.py:386-465.  Differences from hat_arch's: the unfold pads ceil((wse - ws) / 2) (:303-305);
+    `sal` (B,H,W) = the saliency map: tanh of its zero-padded key window is added to every logit of that key (:421-430);
+    top-k pruning (:434-449) keeps the k_keep = max(1, int(ratio * Nk)) keys of a window with the largest score (the focus
+    value, else ||k||_2 over all channels) and REPLACES the other keys' logits by -1e4 before the relative-position bias is
+    added.  `torch.topk(sorted=False)` decides ties exactly as the reference does on this build of torch."""
+    b, h, w, c = q.shape
+    d = c // heads
+    nh, nw = h // ws, w // ws
+    pad = (wse - ws + 1) // 2
+
+    def win_q(x):
+        x = x.reshape(b, nh, ws, nw, ws, heads, d).permute(0, 1, 3, 5, 2, 4, 6)
+        return x.reshape(b * nh * nw, heads, ws * ws, d)
+
+    def unfold(x):  # (B,H,W,Cx) -> (B*nW, Cx, wse*wse), nn.Unfold(kernel wse, stride ws, padding pad)
+        xp = F.pad(x, (0, 0, pad, pad, pad, pad))
+        xs = xp.unfold(1, wse, ws).unfold(2, wse, ws)[:, :nh, :nw]  # (B,nh,nw,Cx,wse,wse)
+        return xs.reshape(b * nh * nw, x.shape[-1], wse * wse)
+
+    kw_, vw_ = unfold(k), unfold(v)                                                       # (B', C, Nk)
+    qh = win_q(q) * scale
+    kh = kw_.reshape(-1, heads, d, wse * wse).permute(0, 1, 3, 2)
+    vh = vw_.reshape(-1, heads, d, wse * wse).permute(0, 1, 3, 2)
+    attn = qh @ kh.transpose(-2, -1)
+    b_, nk = attn.shape[0], wse * wse
+    focus_k = None
+    if sal is not None:
+        focus_k = torch.tanh(unfold(sal[..., None])[:, 0])                                # (B', Nk)
+        attn = attn + focus_k.view(b_, 1, 1, nk)
+    if topk_ratio < 1.0:
+        k_keep = max(1, int(topk_ratio * nk))
+        score = focus_k if focus_k is not None else torch.linalg.vector_norm(kw_.transpose(1, 2), ord=2, dim=-1)
+        idx = torch.topk(score, k_keep, dim=1, sorted=False).indices
+        keep = torch.zeros(b_, nk, dtype=torch.bool).scatter_(1, idx, True)
+        attn = attn.masked_fill(~keep.view(b_, 1, 1, nk), -1e4)
+    bias = table[rpi.reshape(-1)].reshape(ws * ws, wse * wse, heads).permute(2, 0, 1)
+    attn = torch.softmax(attn + bias[None], dim=-1)
+    o = attn @ vh
+    o = o.reshape(b, nh, nw, heads, ws, ws, d).permute(0, 1, 4, 2, 5, 3, 6)
+    return o.reshape(b, h, w, c)
+
+
+def hatx_ocab(t: Tensor, hw, sd: SD, p: str, rpi: Tensor, cfg: dict, heads: int) -> Tensor:
+    """OCAB.forward, hatx_arch.py:367-465."""
+    b, _, c = t.shape
+    ws = cfg["window_size"]
+    wse = int(ws * cfg["overlap_ratio"]) + ws
+    scale = cfg["qk_scale"] or (c // heads) ** -0.5
+    n = _ln(t, sd, p + ".norm1")
+    x_img = n.reshape(b, hw[0], hw[1], c)
+    y_chw = _tok2img(n, hw)
+    if cfg["ocab_esc_enable"]:
+        y_chw = esc_conv_attn(y_chw, sd[p + ".esc_plk"], sd, p + ".esc_core", cfg["ocab_esc_pdim"])
+    y_img = y_chw.permute(0, 2, 3, 1)
+    q = F.linear(x_img, sd[p + ".q_proj.weight"], sd.get(p + ".q_proj.bias"))
+    kv = F.linear(y_img, sd[p + ".kv_proj.weight"], sd.get(p + ".kv_proj.bias"))
+    k, v = kv.split(c, dim=-1)
+    sal = None
+    if cfg["use_focus_bias"]:  # focus_head: 1x1 C -> C/4, GELU, 1x1 -> 1                      :357-361, :423
+        hcw = F.gelu(F.conv2d(y_chw, sd[p + ".focus_head.0.weight"], sd[p + ".focus_head.0.bias"]))
+        sal = F.conv2d(hcw, sd[p + ".focus_head.2.weight"], sd[p + ".focus_head.2.bias"])[:, 0]
+    o = hatx_ocab_attention(q, k, v, sd[p + ".relative_position_bias_table"], rpi, ws, wse, heads, scale, sal, cfg["kv_topk_ratio"])
+    t = F.linear(o.reshape(b, -1, c), sd[p + ".proj.weight"], sd[p + ".proj.bias"]) + t
+    m = _ln(t, sd, p + ".norm2")
+    m = F.linear(F.gelu(F.linear(m, sd[p + ".mlp.0.weight"], sd[p + ".mlp.0.bias"])), sd[p + ".mlp.2.weight"], sd[p + ".mlp.2.bias"])
+    return t + m
+
+
+def hatx_forward(x: Tensor, sd: SD, cfg: dict) -> Tensor:
+    """HATX.forward, hatx_arch.py:944-974: hat_forward with the HATX blocks."""
+    if cfg["upsampler"] != "pixelshuffle":
+        raise NotImplementedError("only the 'pixelshuffle' upsampler is on the hot path")
+    mean = torch.tensor(RGB_MEAN, dtype=x.dtype).view(1, 3, 1, 1) if cfg["in_chans"] == 3 else torch.zeros(1, 1, 1, 1, dtype=x.dtype)
+    r = cfg["img_range"]
+    x = (x - mean) * r
+    f0 = F.conv2d(x, sd["conv_first.weight"], sd["conv_first.bias"], padding=1)
+    hw = (f0.shape[2], f0.shape[3])
+    ws = cfg["window_size"]
+    if hw[0] % ws or hw[1] % ws:
+        raise RuntimeError(f"input size {hw} is not a multiple of window_size {ws}")
+    t = _img2tok(f0)
+    if cfg["patch_norm"]:
+        t = _ln(t, sd, "patch_embed.norm")
+    if "absolute_pos_embed" in sd:
+        t = t + sd["absolute_pos_embed"]
+    rpi = sd["relative_position_index_OCA"]
+    for g, (depth, heads) in enumerate(zip(cfg["depths"], cfg["num_heads"])):
+        t_in, p = t, f"layers.{g}"
+        for i in range(depth):
+            t = hatx_hab(t, hw, sd, f"{p}.residual_group.blocks.{i}", cfg)
+        t = hatx_ocab(t, hw, sd, f"{p}.residual_group.overlap_attn", rpi, cfg, heads)
+        if cfg["resi_connection"] == "1conv":
+            t = _img2tok(F.conv2d(_tok2img(t, hw), sd[p + ".conv.weight"], sd[p + ".conv.bias"], padding=1))
+        t = t + t_in
+    f = _tok2img(_ln(t, sd, "norm"), hw)
+    if cfg["resi_connection"] == "1conv":
+        f = F.conv2d(f, sd["conv_after_body.weight"], sd["conv_after_body.bias"], padding=1)
+    f = f + f0
+    f = F.leaky_relu(F.conv2d(f, sd["conv_before_upsample.0.weight"], sd["conv_before_upsample.0.bias"], padding=1), 0.01)
+    f = upsample(f, sd, cfg["upscale"])
+    return F.conv2d(f, sd["conv_last.weight"], sd["conv_last.bias"], padding=1) / r + mean
+
+
+def hatx_state_dict_spec(cfg: dict) -> Dict[str, tuple]:
+    """Key -> (shape, dtype) of `HATX(**cfg).state_dict()` (hatx_arch.py:714-874), in reference order.  The SGFN is built
+    with `mlp_ratio` (AttenBlocks hands the OCAB ratio to the HABs, hatx_arch.py:513; `hab_ffn_ratio` is stored, not used)."""
+    base = state_dict_spec(cfg)
+    C = cfg["embed_dim"]
+    hid = int(C * cfg["mlp_ratio"])
+    spec: Dict[str, tuple] = {}
+    for k, v in base.items():
+        if ".mlp.fc1.weight" in k:
+            v = ((hid, C), v[1])
+        elif ".mlp.fc1.bias" in k:
+            v = ((hid,), v[1])
+        elif ".mlp.dw.weight" in k:
+            v = ((hid // 2, 1, 3, 3), v[1])
+        elif ".mlp.dw.bias" in k:
+            v = ((hid // 2,), v[1])
+        elif ".mlp.fc2.weight" in k:
+            v = ((C, hid), v[1])
+        spec[k] = v
+        # focus_head sits behind esc_core (or behind mlp.2 when the OCAB has no ESC), hatx_arch.py:342-361
+        if cfg["use_focus_bias"] and ".overlap_attn." in k:
+            last = ".esc_core.aggr.bias" if cfg["ocab_esc_enable"] else ".mlp.2.bias"
+            if k.endswith(last):
+                p = k[: -len(last)]
+                spec[p + ".focus_head.0.weight"] = ((C // 4, C, 1, 1), torch.float32)
+                spec[p + ".focus_head.0.bias"] = ((C // 4,), torch.float32)
+                spec[p + ".focus_head.2.weight"] = ((1, C // 4, 1, 1), torch.float32)
+                spec[p + ".focus_head.2.bias"] = ((1,), torch.float32)
+    return spec
+
+
+def hatx_blank_state_dict(cfg: dict) -> SD:
+    sd: SD = {k: torch.zeros(shape, dtype=dt) for k, (shape, dt) in hatx_state_dict_spec(cfg).items()}
+    sd["relative_position_index_SA"] = rpi_sa(cfg["window_size"])
+    sd["relative_position_index_OCA"] = rpi_oca(cfg["window_size"], cfg["overlap_ratio"])
+    return sd
+
+
+# --------------------------------------------------------------------------------------------
 # caller harness restatement (hat/models/hat_model.py) — cannot be imported (needs basicsr.models)
 # --------------------------------------------------------------------------------------------
 def pre_process(lq: Tensor, window_size: int):
