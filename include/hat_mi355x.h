@@ -194,6 +194,15 @@ int hat_dwconv_gate(const void* u, const float* wdw, const float* bdw, void* out
                     int32_t W, int32_t hid, int32_t ldu, int32_t ldo, int32_t dtype, void* stream);
 
 /*
+ * Spatial-gate step of HATX's SGFN (hatx_arch.py:165-177) between its fc1 and fc2: depthwise 3x3 (+bias, zero pad) on the
+ * FIRST `half` channels of u, gated by SiLU of the second half, which is also passed on:
+ *     out[..., :half] = dw3x3(u[..., :half]) * SiLU(u[..., half:]),   out[..., half:] = u[..., half:].
+ * u: (B,H,W,ldu) T with 2*half channels; wdw packed [9][half] fp32, bdw [half]; out (B,H,W,ldo) T, must not alias u.
+ */
+int hat_sgfn_gate(const void* u, const float* wdw, const float* bdw, void* out, int32_t B, int32_t H, int32_t W,
+                  int32_t half, int32_t ldu, int32_t ldo, int32_t dtype, void* stream);
+
+/*
  * Overlapping cross-attention core (hat_arch.py:353-388): per 'ws x ws' query window and head,
  * softmax(q k^T + RPB) v over the 'wse x wse' key window (stride ws, zero padded, NOT masked).
  * q: (B,H,W,ldq) T (already multiplied by head_dim^-0.5), kv: (B,H,W,ldkv) T with k at channel 0

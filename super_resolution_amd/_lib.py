@@ -106,6 +106,8 @@ SIGNATURES = {
                                 C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p]),
     "hat_dwconv_gate": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32,
                                   C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_void_p]),
+    "hat_sgfn_gate": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32,
+                                C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_void_p]),
     "hat_ocab_attention": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32,
                                      C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32,
                                      C.c_int32, C.c_void_p]),

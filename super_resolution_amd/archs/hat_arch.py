@@ -95,18 +95,29 @@ class _FFN(_Holder):  # hat_arch.py:95-105
         self.fc2 = nn.Linear(hidden, dim)
 
 
-class _HAB(_Holder):  # hat_arch.py:172-215
-    def __init__(self, dim, compress_ratio, mlp_ratio, esc_pdim, esc_kernel):
+class _SGFN(_Holder):  # hatx_arch.py:144-158 (SpatialGateDConvFFN): the depthwise conv covers the first half only
+    def __init__(self, dim, mlp_ratio):
+        super().__init__()
+        hidden = int(dim * mlp_ratio)
+        assert hidden % 2 == 0, f"Hidden({hidden}) must be even for spatial gate split."
+        self.fc1 = nn.Linear(dim, hidden)
+        self.dw = nn.Conv2d(hidden // 2, hidden // 2, 3, 1, 1, groups=hidden // 2)
+        self.fc2 = nn.Linear(hidden, dim)
+
+
+class _HAB(_Holder):  # hat_arch.py:172-215 (sgfn: hatx_arch.py:185-230)
+    def __init__(self, dim, compress_ratio, mlp_ratio, esc_pdim, esc_kernel, sgfn=False):
         super().__init__()
         self.norm1 = nn.LayerNorm(dim)
         self.esc_attn = _ESCAttn(dim, esc_pdim, esc_kernel)
         self.conv_block = _CAB(dim, compress_ratio)
         self.norm2 = nn.LayerNorm(dim)
-        self.mlp = _FFN(dim, mlp_ratio)
+        self.mlp = _SGFN(dim, mlp_ratio) if sgfn else _FFN(dim, mlp_ratio)
 
 
 class _OCAB(_Holder):  # hat_arch.py:267-324
-    def __init__(self, dim, window_size, overlap_ratio, num_heads, qkv_bias, mlp_ratio, esc_enable, esc_pdim, esc_kernel):
+    def __init__(self, dim, window_size, overlap_ratio, num_heads, qkv_bias, mlp_ratio, esc_enable, esc_pdim, esc_kernel,
+                 focus=False):
         super().__init__()
         wse = int(window_size * overlap_ratio) + window_size
         self.norm1 = nn.LayerNorm(dim)
@@ -122,15 +133,17 @@ class _OCAB(_Holder):  # hat_arch.py:267-324
             self.esc_core = _ConvAttnWrapper(dim, esc_pdim)
             self.esc_plk = nn.Parameter(torch.randn(esc_pdim, esc_pdim, esc_kernel, esc_kernel))
             nn.init.orthogonal_(self.esc_plk)
+        if focus:  # hatx_arch.py:357-361: saliency head of the focus bias
+            self.focus_head = nn.Sequential(nn.Conv2d(dim, dim // 4, 1, 1, 0), nn.GELU(), nn.Conv2d(dim // 4, 1, 1, 1, 0))
 
 
 class _AttenBlocks(_Holder):  # hat_arch.py:395-464
     def __init__(self, dim, depth, num_heads, window_size, compress_ratio, overlap_ratio, mlp_ratio, qkv_bias, esc_pdim,
-                 esc_kernel, ocab_esc_enable, ocab_esc_pdim, ocab_esc_kernel):
+                 esc_kernel, ocab_esc_enable, ocab_esc_pdim, ocab_esc_kernel, sgfn=False, focus=False):
         super().__init__()
-        self.blocks = nn.ModuleList([_HAB(dim, compress_ratio, mlp_ratio, esc_pdim, esc_kernel) for _ in range(depth)])
+        self.blocks = nn.ModuleList([_HAB(dim, compress_ratio, mlp_ratio, esc_pdim, esc_kernel, sgfn) for _ in range(depth)])
         self.overlap_attn = _OCAB(dim, window_size, overlap_ratio, num_heads, qkv_bias, mlp_ratio, ocab_esc_enable,
-                                  ocab_esc_pdim, ocab_esc_kernel)
+                                  ocab_esc_pdim, ocab_esc_kernel, focus)
 
 
 class _RHAG(_Holder):  # hat_arch.py:484-553
@@ -174,6 +187,7 @@ class HAT(nn.Module):
     kernel storage/MFMA type (default 'bf16'; 'f32' is the exact-fp32 parity path).  It can also
     be changed later with `set_compute_dtype`.
     """
+    _VARIANT = "hat"
 
     def __init__(self, img_size=64, patch_size=1, in_chans=3, embed_dim=96, depths=(6, 6, 6, 6), num_heads=(6, 6, 6, 6),
                  window_size=7, compress_ratio=3, squeeze_factor=30, conv_scale=0.01, overlap_ratio=0.5, mlp_ratio=4.,
@@ -189,7 +203,9 @@ class HAT(nn.Module):
                         overlap_ratio=overlap_ratio, mlp_ratio=mlp_ratio, qkv_bias=qkv_bias, qk_scale=qk_scale, ape=ape,
                         patch_norm=patch_norm, upscale=upscale, img_range=img_range, upsampler=upsampler,
                         resi_connection=resi_connection, esc_pdim=esc_pdim, esc_kernel=esc_kernel,
-                        ocab_esc_enable=ocab_esc_enable, ocab_esc_pdim=ocab_esc_pdim, ocab_esc_kernel=ocab_esc_kernel)
+                        ocab_esc_enable=ocab_esc_enable, ocab_esc_pdim=ocab_esc_pdim, ocab_esc_kernel=ocab_esc_kernel,
+                        variant=self._VARIANT, kv_topk_ratio=float(kwargs.get("_kv_topk_ratio", 1.0)),
+                        use_focus_bias=bool(kwargs.get("_use_focus_bias", False)))
         self.window_size = window_size
         self.shift_size = window_size // 2
         self.overlap_ratio = overlap_ratio
@@ -218,7 +234,8 @@ class HAT(nn.Module):
             _RHAG(embed_dim, resi_connection, depth=depths[i], num_heads=num_heads[i], window_size=window_size,
                   compress_ratio=compress_ratio, overlap_ratio=overlap_ratio, mlp_ratio=mlp_ratio, qkv_bias=qkv_bias,
                   esc_pdim=esc_pdim, esc_kernel=esc_kernel, ocab_esc_enable=ocab_esc_enable, ocab_esc_pdim=ocab_esc_pdim,
-                  ocab_esc_kernel=ocab_esc_kernel) for i in range(self.num_layers)])
+                  ocab_esc_kernel=ocab_esc_kernel, sgfn=self._VARIANT == "hatx",
+                  focus=bool(kwargs.get("_use_focus_bias", False))) for i in range(self.num_layers)])
         self.norm = norm_layer(embed_dim)
         if resi_connection == '1conv':
             self.conv_after_body = nn.Conv2d(embed_dim, embed_dim, 3, 1, 1)
@@ -347,3 +364,22 @@ class HAT(nn.Module):
             sx.copy_(x)
             g.replay()
             return sy.to(x.dtype, copy=True)
+
+
+@ARCH_REGISTRY.register()
+class HATX(HAT):
+    """Drop-in for the reference's `hat.archs.hatx_arch.HATX` (hatx_arch.py:707-974): `HAT` with the Spatial-Gate DConv FFN
+    (SGFN) in every HAB and an OCAB that pads its key windows with ceil((wse - ws) / 2), may add a focus bias to the logits
+    and may prune keys (top-k).  Same constructor keywords (`hab_ffn_ratio` is accepted and, exactly like the reference,
+    never used: its AttenBlocks hands `mlp_ratio` to the HABs, hatx_arch.py:513), same `state_dict()` surface.
+
+    The MI355X forward covers the SGFN and the OCAB at HATX's default options (kv_topk_ratio = 1, use_focus_bias = False,
+    even window overlap).  The focus bias and top-k pruning are restated and pinned on the CPU oracle only
+    (oracle/hat_oracle.py hatx_ocab_attention): building the engine with them raises NotImplementedError.
+    """
+    _VARIANT = "hatx"
+
+    def __init__(self, *args, hab_ffn_ratio: float = 2.0, kv_topk_ratio: float = 1.0, use_focus_bias: bool = False, **kwargs):
+        self.hab_ffn_ratio = hab_ffn_ratio
+        super().__init__(*args, _kv_topk_ratio=kv_topk_ratio, _use_focus_bias=use_focus_bias, **kwargs)
+        self.kv_topk_ratio, self.use_focus_bias = float(kv_topk_ratio), bool(use_focus_bias)

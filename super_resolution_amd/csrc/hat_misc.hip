@@ -408,6 +408,43 @@ __global__ __launch_bounds__(256) void dwgate_kernel(const T* __restrict__ u, co
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// Spatial-gate step of HATX's SGFN (hatx_arch.py:165-177): depthwise 3x3 + bias on the FIRST `half` channels of u, the
+// second half gates it (SiLU) and is passed on unchanged: out = [dw(a) * silu(b) | b].  4 channels per thread.
+// ---------------------------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(256) void sgfn_gate_kernel(const T* __restrict__ u, const float* __restrict__ wdw,
+                                                        const float* __restrict__ bdw, T* __restrict__ out, int B, int H, int W,
+                                                        int half, int ldu, int ldo) {
+    const int gpp = half / 4;
+    const size_t total = (size_t)B * H * W * gpp;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+        const size_t pix = i / gpp;
+        const int c = (int)(i - pix * gpp) * 4;
+        const int x = (int)(pix % W);
+        const int y = (int)((pix / W) % H);
+        f32x4 a = *reinterpret_cast<const f32x4*>(bdw + c);
+#pragma unroll
+        for (int dy = -1; dy <= 1; ++dy) {
+            const int yy = y + dy;
+            if (yy < 0 || yy >= H) continue;
+#pragma unroll
+            for (int dx = -1; dx <= 1; ++dx) {
+                const int xx = x + dx;
+                if (xx < 0 || xx >= W) continue;
+                const int tap = (dy + 1) * 3 + (dx + 1);
+                a += Vec4<T>::load(u + (size_t)((long)pix + (long)dy * W + dx) * ldu + c) * *reinterpret_cast<const f32x4*>(wdw + (size_t)tap * half + c);
+            }
+        }
+        const f32x4 gt = Vec4<T>::load(u + pix * ldu + half + c);
+        f32x4 o;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) o[r] = a[r] * (gt[r] / (1.0f + expf(-gt[r])));
+        Vec4<T>::store(out + pix * ldo + c, o);
+        Vec4<T>::store(out + pix * ldo + half + c, gt);
+    }
+}
+
 }  // namespace
 
 extern "C" int hat_layernorm_blocks(void) { return LN_BLOCKS; }
@@ -510,6 +547,25 @@ extern "C" int hat_add_f32(const float* a, const float* c, float* out, int32_t B
     const long n4 = n / 4;
     const int blocks = (int)((n4 + 255) / 256 < 4096 ? (n4 + 255) / 256 : 4096);
     HAT_LAUNCH(add_f32_kernel, dim3(blocks, B), dim3(256), 0, s, a, c, out, n4, (long)n, (long)c_bstride);
+    return hat_check_launch();
+}
+
+extern "C" int hat_sgfn_gate(const void* u, const float* wdw, const float* bdw, void* out, int32_t B, int32_t H, int32_t W,
+                             int32_t half, int32_t ldu, int32_t ldo, int32_t dtype, void* stream) {
+    if (!u || !wdw || !bdw || !out || u == out || B < 1 || H < 1 || W < 1 || half < 4 || half % 4 || ldu < 2 * half || ldu % 4 ||
+        ldo < 2 * half || ldo % 4)
+        return HAT_EINVAL;
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    const size_t total = (size_t)B * H * W * (half / 4);
+    const int blocks = (int)((total + 255) / 256 < 8192 ? (total + 255) / 256 : 8192);
+    if (dtype == HAT_BF16)
+        HAT_LAUNCH(sgfn_gate_kernel<bf16_t>, dim3(blocks), dim3(256), 0, s, reinterpret_cast<const bf16_t*>(u), wdw, bdw,
+                   reinterpret_cast<bf16_t*>(out), B, H, W, half, ldu, ldo);
+    else if (dtype == HAT_F32)
+        HAT_LAUNCH(sgfn_gate_kernel<float>, dim3(blocks), dim3(256), 0, s, reinterpret_cast<const float*>(u), wdw, bdw,
+                   reinterpret_cast<float*>(out), B, H, W, half, ldu, ldo);
+    else
+        return HAT_EINVAL;
     return hat_check_launch();
 }
 

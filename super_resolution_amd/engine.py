@@ -87,7 +87,17 @@ class HATEngine:
         ops._lib.load()
         # fused FFN kernel (hat_ffn) for the shapes it is instantiated for; HAT_NO_FUSED_FFN=1 forces the
         # unfused kernel sequence (fc1 -> dw+gate -> fc2), kept for A/B validation of the fusion
-        self.fuse_ffn = ops.ffn_supported(self.C) and os.environ.get("HAT_NO_FUSED_FFN", "0") != "1"
+        self.hatx = cfg.get("variant", "hat") == "hatx"
+        if self.hatx:
+            # HATX (hatx_arch.py): the SGFN runs as fc1 -> hat_sgfn_gate -> fc2; the OCAB at its default options is HAT's.
+            if float(cfg.get("kv_topk_ratio", 1.0)) < 1.0 or cfg.get("use_focus_bias", False):
+                raise NotImplementedError("HATX's focus bias / top-k key pruning (hatx_arch.py:421-449) are restated on the CPU oracle "
+                                          "only (oracle.hat_oracle.hatx_ocab_attention); the MI355X path covers kv_topk_ratio=1.0, "
+                                          "use_focus_bias=False")
+            if (self.wse - self.ws) % 2:
+                raise NotImplementedError("HATX pads odd window overlaps with ceil((wse - ws) / 2) (hatx_arch.py:303-305): only even "
+                                          "overlaps (where it equals HAT's padding) are built")
+        self.fuse_ffn = not self.hatx and ops.ffn_supported(self.C) and os.environ.get("HAT_NO_FUSED_FFN", "0") != "1"
         self._pack(state_dict)
 
     # ------------------------------------------------------------------------------------------
@@ -154,7 +164,7 @@ class HATEngine:
                 if not self.fuse_ffn:
                     hb["fc1"] = self._lin(sd, p + ".mlp.fc1.weight", p + ".mlp.fc1.bias")
                     hb["fc2"] = self._lin(sd, p + ".mlp.fc2.weight", p + ".mlp.fc2.bias")
-                hid2 = sd[p + ".mlp.dw.weight"].shape[0]
+                hid2 = sd[p + ".mlp.dw.weight"].shape[0]     # (HATX: the first half of the SGFN's hidden width)
                 hb["dw_w"] = sd[p + ".mlp.dw.weight"].detach().to(**f32).reshape(hid2, 9).t().contiguous()  # [9][2*hid]
                 hb["dw_b"] = vec(p + ".mlp.dw.bias")
                 if self.fuse_ffn:
@@ -419,8 +429,12 @@ class HATEngine:
                     ln(tB, w["n"], hb["n2"])
                     hid2 = hb["fc1"].nout
                     self._run_lin(hb["fc1"], w["n"], w["u"], **geo, ldx=ldc, ldo=w["u"].shape[2])
-                    ops.dwconv_gate(w["u"], hb["dw_w"], hb["dw_b"], w["g"], B=B, H=H, W=W, hid=hid2 // 2, ldu=w["u"].shape[2],
-                                    ldo=w["g"].shape[2], dtype=dt)
+                    if self.hatx:   # SGFN: [dw(a) * silu(b) | b], hid2 channels in and out            hatx_arch.py:165-177
+                        ops.sgfn_gate(w["u"], hb["dw_w"], hb["dw_b"], w["g"], B=B, H=H, W=W, half=hid2 // 2, ldu=w["u"].shape[2],
+                                      ldo=w["g"].shape[2], dtype=dt)
+                    else:
+                        ops.dwconv_gate(w["u"], hb["dw_w"], hb["dw_b"], w["g"], B=B, H=H, W=W, hid=hid2 // 2, ldu=w["u"].shape[2],
+                                        ldo=w["g"].shape[2], dtype=dt)
                     self._run_lin(hb["fc2"], w["g"], tB, **geo, ldx=w["g"].shape[2], ldo=C, out_mode=O_NHWC_F32, r1=tB, ldr1=C)
                     t, have_n = tB, False
             esc = oc.get("esc")  # OCAB                                                    :326-393

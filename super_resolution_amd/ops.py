@@ -210,6 +210,13 @@ def dwconv_gate(u, wdw, bdw, out, *, B: int, H: int, W: int, hid: int, ldu: int,
         "hat_dwconv_gate"))
 
 
+def sgfn_gate(u, wdw, bdw, out, *, B: int, H: int, W: int, half: int, ldu: int, ldo: int, dtype: int):
+    """HATX SGFN: out = [dw3x3(u[:half]) * silu(u[half:]) | u[half:]] (hat_sgfn_gate)."""
+    lib = _lib.load()
+    _timed(f"sgfn_gate_kernel<{_TNAME[dtype]}>", 2.0 * 9 * half * B * H * W, lambda: _lib.check(
+        lib.hat_sgfn_gate(_ptr(u), _ptr(wdw), _ptr(bdw), _ptr(out), B, H, W, half, ldu, ldo, dtype, _stream()), "hat_sgfn_gate"))
+
+
 def ocab_attention(q, kv, bias_rot, out, *, B: int, H: int, W: int, C_: int, heads: int, ws: int, wse: int, ldq: int,
                    ldkv: int, ldo: int, dtype: int):
     lib = _lib.load()

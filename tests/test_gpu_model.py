@@ -65,6 +65,40 @@ def test_whole_model_vs_reference_golden(name, dtype):
 
 
 @pytest.mark.parametrize("dtype", ["f32", "bf16"])
+def test_hatx_default_options_vs_reference_golden(dtype):
+    """the HATX drop-in at its default attention options (SGFN in every HAB through hat_sgfn_gate; OCAB =
+    HAT's) against the whole-model output of the reference's own HATX (tests/golden/gen_golden_hatx.py)."""
+    dev = _dev()
+    from super_resolution_amd.registry import build_network
+    g = golden("whole_hatx_tiny_plain_x2.npz")
+    net = build_network(dict(type="HATX", compute_dtype=dtype, **META["cfgs"]["hatx_tiny_plain_x2"])).eval()
+    net.load_state_dict(synth.synth_state_dict(net.state_dict(), W_SEED), strict=True)
+    y = net.to(dev)(synth.synth_input(X_SEED, tuple(g["x_shape"])).to(dev))
+    torch.cuda.synchronize()
+    assert_close(y, g["y"], dtype, f"HATX tiny/{dtype} vs reference golden")
+
+
+def test_hatx_sgfn_c144_vs_oracle_and_unbuilt_options_fail_loudly():
+    """HATX at embed_dim 144 (SGFN 144 -> 288 -> [144 | 144] -> 144 on the tuned linears) against the CPU oracle; the focus
+    bias / top-k options, which only the oracle implements, raise instead of silently running something else."""
+    dev = _dev()
+    from super_resolution_amd.registry import build_network
+    kw = dict(META["cfgs"]["hats_1g_x4"], depths=[2], upscale=2)
+    cfg = O.make_hatx_cfg(**kw)
+    sd = synth.synth_state_dict(O.hatx_blank_state_dict(cfg), W_SEED)
+    x = synth.synth_input(5, (1, 3, 32, 48))
+    ref = O.hatx_forward(x, sd, cfg)
+    net = build_network(dict(type="HATX", compute_dtype="bf16", **kw)).eval()
+    net.load_state_dict(sd, strict=True)
+    y = net.to(dev)(x.to(dev))
+    torch.cuda.synchronize()
+    assert_close(y, ref, "bf16", "HATX C=144 vs oracle")
+    bad = build_network(dict(type="HATX", **META["cfgs"]["hatx_tiny_focus_x2"])).eval().to(dev)
+    with pytest.raises(NotImplementedError):
+        bad(torch.rand(1, 3, 16, 24, device=dev))
+
+
+@pytest.mark.parametrize("dtype", ["f32", "bf16"])
 def test_cfg1_hats_x2_64_vs_reference_golden(dtype):
     """BASELINE config 1: HAT-S x2 on a 3x64x64 LR tile."""
     dev = _dev()

@@ -37,6 +37,17 @@ def test_product_state_dict_equals_reference_surface(name):
     assert int(sd["relative_position_index_OCA"].min()) < 0
 
 
+@pytest.mark.parametrize("name", ["hatx_tiny_plain_x2", "hatx_tiny_focus_x2", "hatx_train_yml"])
+def test_product_hatx_state_dict_equals_reference_surface(name):
+    """The HATX drop-in (registered as 'HATX', hatx_arch.py:707): keys, order, shapes, dtypes, parameter count of the
+    reference's HATX for two tiny configs and for the fork's one live training config (SGFN, focus head, ESC in the OCAB)."""
+    with open(os.path.join(GOLDEN, "state_dict_surface.json")) as f:
+        surf = json.load(f)
+    net = build_network(dict(type="HATX", **META["cfgs"][name]))
+    assert [[k, list(v.shape), str(v.dtype)] for k, v in net.state_dict().items()] == surf[name]
+    assert sum(p.numel() for p in net.parameters()) == surf[name + ":nparams"]
+
+
 def test_unknown_resi_connection_raises_at_build_time():
     with pytest.raises(ValueError):
         build_network(dict(type="HAT", **dict(META["cfgs"]["tiny_x2"], resi_connection="3conv")))
