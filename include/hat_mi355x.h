@@ -344,6 +344,26 @@ typedef struct HatHabTailDesc {
 } HatHabTailDesc;
 int hat_hab_tail(const HatHabTailDesc* d, void* stream);
 
+/*
+ * Forward plans — the whole network behind three calls, for hosts without Python (SURVEY §8b's hat_forward(handle ...)).
+ * A plan file holds ONE input shape's complete forward: every call of this header in launch order with its descriptors
+ * and scalars, every device pointer as (buffer, offset), the packed weights and constants with their bytes, and the sizes
+ * of the workspace buffers.  `python -m super_resolution_amd.plan -opt x.yml --shape B H W -o net.hatplan` (or
+ * `super_resolution_amd.plan.export_plan(net, shape, path)`) writes it by recording what the engine launches.
+ *   hat_plan_load     reads the file, allocates (hipMalloc) and uploads; *out owns the device memory.
+ *   hat_plan_info     dims8 = {B, Cin, H, W, scale, Cout, dtype, 0}; number of launches; device bytes held.
+ *   hat_plan_forward  x: (B,Cin,H,W) fp32 NCHW in [0,1], y: (B,Cout,scale*H,scale*W) fp32, both device memory of that
+ *                     shape; issues the recorded launches on `stream` (one stream; no allocation, no sync).  Results
+ *                     are bit-identical to the Python engine's for the same weights.  Not re-entrant per plan (the
+ *                     workspace is the plan's): one forward at a time.
+ *   hat_plan_free     releases everything.
+ */
+typedef struct hat_plan hat_plan;
+int hat_plan_load(const char* path, hat_plan** out);
+int hat_plan_info(const hat_plan* plan, int32_t* dims8, int64_t* n_calls, int64_t* device_bytes);
+int hat_plan_forward(const hat_plan* plan, const float* x, float* y, void* stream);
+void hat_plan_free(hat_plan* plan);
+
 int hat_abi_version(void);
 /* name of the architecture the code objects in this library were compiled for ("gfx950") */
 const char* hat_target_arch(void);

@@ -96,6 +96,10 @@ SIGNATURES = {
     "hat_ffn": (C.c_int, [C.POINTER(HatFfnDesc), C.c_void_p]),
     "hat_ffn2": (C.c_int, [C.POINTER(HatFfnDesc), C.c_void_p]),
     "hat_hab_tail": (C.c_int, [C.POINTER(HatHabTailDesc), C.c_void_p]),
+    "hat_plan_load": (C.c_int, [C.c_char_p, C.POINTER(C.c_void_p)]),
+    "hat_plan_info": (C.c_int, [C.c_void_p, C.POINTER(C.c_int32), C.POINTER(C.c_int64), C.POINTER(C.c_int64)]),
+    "hat_plan_forward": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "hat_plan_free": (None, [C.c_void_p]),
     "hat_layernorm_blocks": (C.c_int, []),
     "hat_layernorm": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int64,
                                 C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_void_p]),

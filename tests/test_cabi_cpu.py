@@ -119,3 +119,19 @@ def test_registry_semantics():
         r.register(A)
     with pytest.raises(KeyError):
         r.get("missing")
+
+
+def test_c_host_example_compiles_and_links_with_plain_gcc(tmp_path):
+    """examples/plan_forward.c — the whole network from a C host through hat_plan_* — builds with gcc against the in-tree
+    library and the HIP runtime (it is RUN on the GPU box by tests/test_gpu_plan.py)."""
+    import shutil
+    import subprocess
+    if not shutil.which("gcc") or not os.path.exists("/opt/rocm/include/hip/hip_runtime_api.h"):
+        pytest.skip("needs gcc and the ROCm headers")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = tmp_path / "plan_forward"
+    r = subprocess.run(["gcc", os.path.join(root, "examples", "plan_forward.c"), "-I" + os.path.join(root, "include"), "-I/opt/rocm/include",
+                        "-D__HIP_PLATFORM_AMD__", "-L" + os.path.join(root, "super_resolution_amd"), "-lhat_mi355x", "-L/opt/rocm/lib",
+                        "-lamdhip64", "-Wl,-rpath," + os.path.join(root, "super_resolution_amd"), "-o", str(out)], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert out.exists()
