@@ -179,6 +179,15 @@ int hat_esc_weights(const float* gap_partial, int32_t nblk, int64_t npix, const 
                     int32_t pdim, int32_t ksize, int32_t Kpad, int32_t dtype, void* stream);
 
 /*
+ * The ESC large-kernel conv as a dedicated kernel (esc_arch.py:121-123), bf16, pdim 16, 13x13: y16 = conv2d(x[..., :16], Wp[b])
+ * with zero padding 6, no bias.  x: (B,H,W,ldx) T (the first 16 channels are used); wp: hat_esc_weights' output
+ * [B][16][Kpad] (K = tap * 16 + ci, tap = ty * 13 + tx); y16: (B,H,W,16) T.  All weights and the haloed tile stay in LDS.
+ * HAT_EUNSUPPORTED for other dtypes: use hat_conv (ksize 13).
+ */
+int hat_esc_conv13(const void* x, int32_t ldx, const void* wp, int32_t Kpad, void* y16, int32_t B, int32_t H, int32_t W,
+                   int32_t dtype, void* stream);
+
+/*
  * ECA channel attention scale (hat_arch.py:73-77) times conv_scale (:236):
  * scale[b][c] = conv_scale * sigmoid( conv1d_k(mean_pixels(c2))[c] ), from hat_conv's colsum.
  * `tmp` is fp32 scratch of B*32*ldc floats.

@@ -1,0 +1,137 @@
+// hat_esc13.hip — the ESC large-kernel conv (13x13, 16 -> 16 channels, per-sample weights: static filter + dynamic depthwise
+// 3x3 on its centre; esc_arch.py:121-123) as a dedicated kernel (contract: hat_esc_conv13 in include/hat_mi355x.h).
+//
+// hat_conv runs this layer as a one-n-tile implicit GEMM: a fresh 1 KB activation fragment AND half a weight fragment per
+// MFMA from LDS, weight chunks streamed through LDS behind a barrier each — 0.19 ms at 720p for 80 GFLOP, four times its
+// own LDS / MFMA floors, and it sits on every HAB's critical path.  Here:
+//   * ALL weights are resident in LDS for the life of a (persistent) workgroup: 91 A fragments = 7 column pairs x 13 tap rows
+//     (the 13 taps of a row are paired as (0,1) .. (10,11), (12, zero)), copied in once by LDS-DMA straight from the
+//     [16][169 * 16] rows hat_esc_weights writes (the fragment order is a gather of 16-byte pieces; the zero tap comes
+//     from a zero page);
+//   * the haloed input tile (44 x 44 pixels x 16 channels, 32 bytes per pixel: lane (p, g) -> pixel p + tap column, half
+//     g & 1 is conflict-free for ds_read_b128) is resident too: no barrier inside the K loop;
+//   * a wave owns two output rows x 32 columns and sweeps the tap ROWS for a fixed column pair: the input-row fragment that
+//     output row 1 uses for tap row dy is the one output row 0 needs for tap row dy + 1, so 14 row fragments feed 26
+//     k-steps: 0.79 KB of LDS reads per MFMA instead of 1.5;
+//   * 16 waves per workgroup (4 per SIMD, < 64 registers each) hide the LDS latency.
+#include "hat_common.h"
+
+namespace {
+
+constexpr int E_TR = 32, E_TC = 32, E_WAVES = 16, E_HALO = 6;
+constexpr int E_HR = E_TR + 2 * E_HALO, E_HC = E_TC + 2 * E_HALO;      // 44 x 44 haloed pixels
+constexpr int E_NFRAG = 7 * 13;
+constexpr int E_X_OFF = E_NFRAG * 1024;                                  // 93184
+constexpr int E_LDS = E_X_OFF + E_HR * E_HC * 32 + 64;                   // 155200 bytes (one workgroup per CU)
+
+__device__ __attribute__((aligned(16))) unsigned hat_esc13_zero_page[4] = {0, 0, 0, 0};
+
+__global__ __launch_bounds__(E_WAVES * 64) void esc13_kernel(const bf16_t* __restrict__ x, int ldx, const bf16_t* __restrict__ wp, int Kpad,
+                                                             bf16_t* __restrict__ y16, int H, int W, int tiles_x, int ntiles) {
+    typedef __bf16 bf8 __attribute__((ext_vector_type(8)));
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    typedef __attribute__((address_space(3))) char lds_char;
+    const unsigned lds0 = (unsigned)(uintptr_t)(lds_char*)smem;
+    const int tid = threadIdx.x, lane = tid & 63, g = lane >> 4, c16 = lane & 15;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int b = blockIdx.y;
+    const bf16_t* xb = x + (size_t)b * H * W * ldx;
+    bf16_t* yb = y16 + (size_t)b * H * W * 16;
+    // ---- weights -> LDS, once: fragment s = dxp * 13 + dy holds taps (dy, 2 dxp) and (dy, 2 dxp + 1) -----------------------
+    {
+        const bf16_t* wrow = wp + ((size_t)b * 16 + c16) * Kpad;
+        for (int s = wave; s < E_NFRAG; s += E_WAVES) {
+            const int dxp = s / 13, dy = s - 13 * dxp, dx = 2 * dxp + (g >> 1);
+            const char* src = dx <= 12 ? reinterpret_cast<const char*>(wrow + (dy * 13 + dx) * 16 + 8 * (g & 1))
+                                       : reinterpret_cast<const char*>(hat_esc13_zero_page);
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                             (__attribute__((address_space(3))) void*)(smem + s * 1024), 16, 0, 0);
+        }
+        if (tid < 4) *reinterpret_cast<u32x4*>(smem + E_LDS - 64 + tid * 16) = u32x4{0u, 0u, 0u, 0u};
+    }
+    const int r0 = 2 * wave;
+    // lane (p, g): pixel column c16 + (g >> 1) (the second tap of a pair is one column further), channel half g & 1
+    const unsigned xbase = lds0 + E_X_OFF + (unsigned)((r0 * E_HC + c16 + (g >> 1)) * 32 + (g & 1) * 16);
+    const unsigned abase = lds0 + (unsigned)lane * 16u;
+
+    // The next tile's haloed input is fetched into registers BEFORE this tile's K loop and written to LDS after it: with one
+    // workgroup per CU nothing else would cover that latency.
+    constexpr int NPIECE = E_HR * E_HC * 2, NIT = (NPIECE + E_WAVES * 64 - 1) / (E_WAVES * 64);
+    u32x4 pv[NIT];
+    auto fetch = [&](int t) {
+        const int tc = min(t, ntiles - 1);
+        const int ty0 = (tc / tiles_x) * E_TR, tx0 = (tc - (tc / tiles_x) * tiles_x) * E_TC;
+#pragma unroll
+        for (int it = 0; it < NIT; ++it) {
+            const int i = min(tid + it * E_WAVES * 64, NPIECE - 1);
+            const int hp = i >> 1, half = i & 1;
+            const int hy = hp / E_HC, hx = hp - hy * E_HC;
+            const int y = ty0 - E_HALO + hy, xx = tx0 - E_HALO + hx;
+            const bool in = y >= 0 && y < H && xx >= 0 && xx < W;
+            const u32x4 v = *reinterpret_cast<const u32x4*>(xb + ((size_t)min(max(y, 0), H - 1) * W + min(max(xx, 0), W - 1)) * ldx + half * 8);
+            pv[it] = in ? v : u32x4{0u, 0u, 0u, 0u};
+        }
+    };
+    fetch(blockIdx.x);
+    for (int t = blockIdx.x; t < ntiles; t += gridDim.x) {
+        const int ty0 = (t / tiles_x) * E_TR, tx0 = (t - (t / tiles_x) * tiles_x) * E_TC;
+#pragma unroll
+        for (int it = 0; it < NIT; ++it) {
+            const int i = tid + it * E_WAVES * 64;
+            if (i < NPIECE) *reinterpret_cast<u32x4*>(smem + E_X_OFF + i * 16) = pv[it];
+        }
+        __syncthreads();   // (first tile: also drains the weight copy)
+        fetch(t + gridDim.x);   // in flight during the K loop (clamped to a valid tile past the end)
+
+        f32x4 acc[2][2];
+#pragma unroll
+        for (int pt = 0; pt < 2; ++pt)
+#pragma unroll
+            for (int ct = 0; ct < 2; ++ct) acc[pt][ct] = f32x4{0.f, 0.f, 0.f, 0.f};
+        auto ldb = [&](int rr, int dxp, int ct) {
+            return __builtin_bit_cast(bf8, *(__attribute__((address_space(3))) const u32x4*)(uintptr_t)(xbase + (unsigned)((rr * E_HC) * 32 + dxp * 64 + ct * 512)));
+        };
+#pragma unroll
+        for (int dxp = 0; dxp < 7; ++dxp) {
+            bf8 prev[2] = {ldb(0, dxp, 0), ldb(0, dxp, 1)};
+#pragma unroll
+            for (int dy = 0; dy < 13; ++dy) {
+                const bf8 a = __builtin_bit_cast(bf8, *(__attribute__((address_space(3))) const u32x4*)(uintptr_t)(abase + (unsigned)((dxp * 13 + dy) * 1024)));
+                const bf8 nx[2] = {ldb(dy + 1, dxp, 0), ldb(dy + 1, dxp, 1)};
+#pragma unroll
+                for (int ct = 0; ct < 2; ++ct) {
+                    acc[0][ct] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, prev[ct], acc[0][ct], 0, 0, 0);
+                    acc[1][ct] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, nx[ct], acc[1][ct], 0, 0, 0);
+                }
+                prev[0] = nx[0];
+                prev[1] = nx[1];
+            }
+        }
+        // ---- store: lane holds channels 4g..4g+3 of pixel c16 of each of its four 16-pixel tiles ---------------------------
+#pragma unroll
+        for (int pt = 0; pt < 2; ++pt)
+#pragma unroll
+            for (int ct = 0; ct < 2; ++ct) {
+                const int y = ty0 + r0 + pt, xx = tx0 + ct * 16 + c16;
+                if (y < H && xx < W) Vec4<bf16_t>::store(yb + ((size_t)y * W + xx) * 16 + 4 * g, acc[pt][ct]);
+            }
+        __syncthreads();   // every wave is done with the input tile before the next one overwrites it
+    }
+}
+
+}  // namespace
+
+extern "C" int hat_esc_conv13(const void* x, int32_t ldx, const void* wp, int32_t Kpad, void* y16, int32_t B, int32_t H, int32_t W,
+                              int32_t dtype, void* stream) {
+    if (!x || !wp || !y16 || B < 1 || H < 1 || W < 1 || ldx < 16 || ldx % 8 || Kpad < 169 * 16 || Kpad % 8) return HAT_EINVAL;
+    if (dtype != HAT_BF16) return HAT_EUNSUPPORTED;
+    auto kern = esc13_kernel;
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, E_LDS);
+    if (e != hipSuccess) return (int)e;
+    const int tiles_x = (W + E_TC - 1) / E_TC, tiles_y = (H + E_TR - 1) / E_TR, ntiles = tiles_x * tiles_y;
+    int gx = 256 / (B < 2 ? 1 : (B < 4 ? 2 : 4));
+    if (gx > ntiles) gx = ntiles;
+    HAT_LAUNCH(kern, dim3(gx, B), dim3(E_WAVES * 64), E_LDS, reinterpret_cast<hipStream_t>(stream), reinterpret_cast<const bf16_t*>(x), ldx,
+               reinterpret_cast<const bf16_t*>(wp), Kpad, reinterpret_cast<bf16_t*>(y16), H, W, tiles_x, ntiles);
+    return hat_check_launch();
+}

@@ -289,6 +289,9 @@ class HATEngine:
                         pdim=esc.pdim, ksize=esc.ksize, kpad=esc.kpad, dtype=self.dtype)
 
     def _esc_conv(self, esc: _ESC, w, n, B, H, W):
+        if ops.esc_conv13_supported(esc.pdim, esc.ksize, self.dtype) and os.environ.get("HAT_NO_ESC13") != "1":
+            ops.esc_conv13(n, w["weff"], w["y16"], B=B, H=H, W=W, ldx=_r8(self.C), kpad=esc.kpad, dtype=self.dtype)
+            return
         pw = ops.PackedConv(w["weff"], esc.zero_bias, esc.ksize, esc.pdim, esc.kpad, 1, 1, esc.pdim,
                             w_bstride=16 * esc.kpad)
         ops.conv(pw, n, w["y16"], B=B, H=H, W=W, dtype=self.dtype, ldx=_r8(self.C), ldo=16, n_store=_r4(esc.pdim))

@@ -196,6 +196,18 @@ def esc_weights(gap: torch.Tensor, nblk: int, npix: int, w1, b1, w2, b2, plk_pac
                             pdim, ksize, kpad, dtype, _stream()), "hat_esc_weights"))
 
 
+def esc_conv13_supported(pdim: int, ksize: int, dtype: int) -> bool:
+    return pdim == 16 and ksize == 13 and dtype == HAT_BF16
+
+
+def esc_conv13(x, wp, y16, *, B: int, H: int, W: int, ldx: int, kpad: int, dtype: int):
+    """ESC 13x13 conv on the dedicated kernel (hat_esc_conv13): weights and haloed tile resident in LDS."""
+    lib = _lib.load()
+    _timed("esc13_kernel", 2.0 * B * H * W * 169 * 256 + 2.0 * 9 * 16 * B * H * W, lambda: _lib.check(
+        lib.hat_esc_conv13(_ptr(x), ldx, _ptr(wp), kpad, _ptr(y16), B, H, W, dtype, _stream()), "hat_esc_conv13"),
+        tag=f"k13 16->16 {H}x{W} resident")
+
+
 def eca_scale(colsum, tiles: int, ldc: int, npix: int, wk, k: int, conv_scale: float, tmp, scale, *, B: int, C_: int):
     lib = _lib.load()
     _timed("eca_reduce+scale", 0.0, lambda: _lib.check(

@@ -597,6 +597,36 @@ def test_aggr_with_folded_cab(geom):
     check(out.reshape(B, H, W, C), ref, dtype, "aggr + folded cab")
 
 
+@pytest.mark.parametrize("geom", [(1, 64, 96), (2, 45, 70), (1, 8, 8), (1, 33, 129)], ids=["64x96", "B2_ragged_45x70", "8x8", "33x129"])
+def test_esc_conv13_resident(geom):
+    """hat_esc_conv13 (the ESC large-kernel conv with all weights and the haloed tile resident in LDS, esc_arch.py:121-123)
+    against conv2d in fp64 with per-sample weights in hat_esc_weights' [B][16][Kpad] layout, and against hat_conv (ksize 13),
+    the path it replaces: several tiles per workgroup, frames smaller than a tile, ragged edges, B = 2."""
+    B, H, W = geom
+    dev, ops = _dev(), _ops()
+    dt = ops.DTYPE_CODE["bf16"]
+    C, pd, ks = 144, 16, 13
+    x = q(rnd("e13x", (B, H, W, C)), "bf16")
+    wt = q(rnd("e13w", (B, pd, pd, ks, ks), std=(pd * ks * ks) ** -0.5), "bf16")          # [b][co][ci][ty][tx]
+    ref = torch.cat([F.conv2d(x[i:i + 1, ..., :pd].permute(0, 3, 1, 2).double(), wt[i].double(), padding=ks // 2) for i in range(B)], 0)
+    ref = ref.permute(0, 2, 3, 1)
+    kc = ops.KC[dt] * 3
+    kpad = -(-(ks * ks * pd) // kc) * kc
+    wp = torch.zeros(B, 16, kpad)
+    wp[:, :pd, :ks * ks * pd] = wt.permute(0, 1, 3, 4, 2).reshape(B, pd, ks * ks * pd)     # K = tap * 16 + ci
+    wpd = wp.to(torch.bfloat16).to(dev).contiguous()
+    xd = to_dev(x, C, torch.bfloat16, dev)
+    y = torch.full((B, H * W, 16), 3.0, dtype=torch.bfloat16, device=dev)
+    ops.esc_conv13(xd, wpd, y, B=B, H=H, W=W, ldx=C, kpad=kpad, dtype=dt)
+    torch.cuda.synchronize()
+    check(y.reshape(B, H, W, 16).float(), ref, "bf16", "esc conv13 vs fp64")
+    pw = ops.PackedConv(wpd, torch.zeros(16, device=dev), ks, pd, kpad, 1, 1, pd, w_bstride=16 * kpad)
+    y2 = torch.zeros_like(y)
+    ops.conv(pw, xd, y2, B=B, H=H, W=W, dtype=dt, ldx=C, ldo=16, n_store=16)
+    torch.cuda.synchronize()
+    assert float((y.float() - y2.float()).abs().max()) <= 0.04 * max(1.0, float(y2.float().abs().max()))   # two bf16 roundings of the same sums
+
+
 @pytest.mark.parametrize("geom", [(2, 24, 40), (1, 19, 27), (1, 8, 16), (1, 35, 64)], ids=["B2_24x40", "ragged_19x27", "one_tile", "35x64"])
 def test_hab_tail_fused(geom):
     """hat_hab_tail = hat_aggr_cab + hat_ffn2 in one launch (hat_arch.py:233-237, esc_arch.py:123): t + aggr([y16 | n[16:]]) +
