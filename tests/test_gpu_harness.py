@@ -60,3 +60,38 @@ def test_cli_end_to_end(tmp_path, tile):
         psnrs.append(O.psnr_y(ref8, gt8, 2))
         assert res["Toy"]["images"][i]["psnr"] == pytest.approx(psnrs[-1], abs=1e-3)  # north_star: within 1e-3 dB
     assert res["Toy"]["mean"]["psnr"] == pytest.approx(float(np.mean(psnrs)), abs=1e-3)
+
+
+def test_tiled_720p_allocates_one_workspace_per_distinct_tile_shape():
+    """VERDICT r1 (host side): `HATModel.tile_process` with the reference grid on a 720x1280 frame at tile_size 256 /
+    tile_pad 32 — 15 tiles of 6 distinct padded shapes (interior, edges, corners, the 208-row last band) — must allocate the
+    engine workspace once per distinct shape (LRU), not once per tile, and a second frame must allocate nothing."""
+    if not torch.cuda.is_available():
+        pytest.skip("needs an MI355X")
+    from super_resolution_amd.models import HATModel
+    from super_resolution_amd import tile_parallel as tp
+    net_opt = dict(type="HAT", upscale=2, in_chans=3, img_size=64, window_size=16, compress_ratio=24, squeeze_factor=24,
+                   conv_scale=0.01, overlap_ratio=0.5, img_range=1.0, depths=[1], embed_dim=144, num_heads=[6], mlp_ratio=2,
+                   upsampler="pixelshuffle", resi_connection="1conv", compute_dtype="bf16")
+    model = HATModel({"name": "t", "scale": 2, "network_g": net_opt, "path": {}, "tile": {"tile_size": 256, "tile_pad": 32}}, device="cuda:0")
+    shapes = {(t.py1 - t.py0, t.px1 - t.px0) for t in tp.reference_tiles(720, 1280, 256, 32)}
+    for k in range(2):
+        model.feed_data({"lq": synth.synth_input(50 + k, (1, 3, 720, 1280))})
+        model.test()
+        torch.cuda.synchronize()
+        assert model.output.shape == (1, 3, 1440, 2560) and torch.isfinite(model.output).all()
+        assert model.net_g.engine().ws_allocations == len(shapes), (model.net_g.engine().ws_allocations, len(shapes))
+
+
+def test_dataparallel_wrapper_on_one_gpu():
+    """base_model.py:99-100 wraps the network in nn.DataParallel when num_gpu > 1; with one visible device that is a plain
+    call-through and must give the same result as the bare module."""
+    if not torch.cuda.is_available():
+        pytest.skip("needs an MI355X")
+    from super_resolution_amd.registry import build_network
+    net = build_network(dict(NET, compute_dtype="f32")).eval().to("cuda:0")
+    x = synth.synth_input(3, (1, 3, 32, 48)).to("cuda:0")
+    y = net(x)
+    yd = torch.nn.DataParallel(net, device_ids=[0])(x)
+    torch.cuda.synchronize()
+    assert torch.equal(y, yd)
