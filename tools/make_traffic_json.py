@@ -8,7 +8,7 @@ import csv, glob, json, re, sys, collections
 fdir, wdir, out, model, scale, H, W, dtype = sys.argv[1:9]
 BENCH_NAME = [  # rocprof kernel-name pattern -> the name bench.py prints
     (r"ffn2_kernelILi0ELb1E|ffn2_kernel<0, true", "ffn2_kernel<aggr>"), (r"ffn2_kernel", "ffn2_kernel"),
-    (r"ffn_kernel", "ffn_kernel<__bf16>"), (r"ocab_attn", "ocab_attn_kernel<__bf16>"), (r"aggr_cab_kernel", "aggr_cab_kernel"),
+    (r"esc13_kernel", "esc13_kernel"), (r"ffn_kernel", "ffn_kernel<__bf16>"), (r"ocab_attn", "ocab_attn_kernel<__bf16>"), (r"aggr_cab_kernel", "aggr_cab_kernel"),
     (r"pw_kernel.*ELi5E", "pw_kernel<__bf16, 9, 5>"), (r"pw_kernel.*ELi9E", "pw_kernel<__bf16, 9, 9>"),
     (r"cab_squeeze_kernel(ILi5E|<5)", "cab_squeeze_kernel"), (r"cab_squeeze_kernel(ILi2E|<2)", "cab_squeeze_kernel<2, planes>"),
     (r"tap3_kernel.*41, 144", "tap3_kernel<__bf16, 1>"), (r"tap3_kernel.*ELi3ELi8E", "tap3_kernel<__bf16, 9>"),
