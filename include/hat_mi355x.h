@@ -203,6 +203,22 @@ int hat_dwconv_gate(const void* u, const float* wdw, const float* bdw, void* out
                     int32_t W, int32_t hid, int32_t ldu, int32_t ldo, int32_t dtype, void* stream);
 
 /*
+ * HATX's OCAB options (hatx_arch.py:421-449), for window sizes the generic attention kernel is built for (wse % 4 == 0):
+ *   hat_ocab_keybias      kb[b][window][key] (fp32, wse*wse per window) = tanh(sal at the key's pixel) for a kept key — 0
+ *                         without a focus head (sal == NULL: the score is then ||k||_2 over the C key channels of kv) —
+ *                         and -inf for a pruned one; kept = the k_keep keys of a window with the largest score, ties by
+ *                         the lower key index (the reference leaves tie order to torch.topk); zero-padded keys outside
+ *                         the image score tanh(0) = 0 / norm 0.  sal: (B,H,W,ldsal) T, channel 0 = the saliency map.
+ *   hat_ocab_attention_kb hat_ocab_attention with `kb` applied before the relative-position bias: logit + kb, or -1e4 in
+ *                         place of the logit where kb = -inf; `pad` = ceil((wse - ws) / 2), HATX's unfold padding.
+ */
+int hat_ocab_keybias(const void* sal, int32_t ldsal, const void* kv, int32_t ldkv, float* kb, int32_t B, int32_t H, int32_t W,
+                     int32_t C, int32_t ws, int32_t wse, int32_t pad, int32_t k_keep, int32_t dtype, void* stream);
+int hat_ocab_attention_kb(const void* q, const void* kv, const float* bias_rot, const float* kb, void* out, int32_t B, int32_t H,
+                          int32_t W, int32_t C, int32_t heads, int32_t ws, int32_t wse, int32_t pad, int32_t ldq, int32_t ldkv,
+                          int32_t ldo, int32_t dtype, void* stream);
+
+/*
  * Spatial-gate step of HATX's SGFN (hatx_arch.py:165-177) between its fc1 and fc2: depthwise 3x3 (+bias, zero pad) on the
  * FIRST `half` channels of u, gated by SiLU of the second half, which is also passed on:
  *     out[..., :half] = dw3x3(u[..., :half]) * SiLU(u[..., half:]),   out[..., half:] = u[..., half:].

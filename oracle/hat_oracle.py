@@ -432,7 +432,7 @@ def hatx_hab(t: Tensor, hw, sd: SD, p: str, cfg: dict) -> Tensor:
 
 
 def hatx_ocab_attention(q: Tensor, k: Tensor, v: Tensor, table: Tensor, rpi: Tensor, ws: int, wse: int, heads: int, scale: float,
-                        sal: Optional[Tensor] = None, topk_ratio: float = 1.0) -> Tensor:
+                        sal: Optional[Tensor] = None, topk_ratio: float = 1.0, tie: str = "torch") -> Tensor:
     """Attention core of hatx_arch.py:386-465.  Differences from hat_arch's: the unfold pads ceil((wse - ws) / 2) (:303-305);
     `sal` (B,H,W) = the saliency map: tanh of its zero-padded key window is added to every logit of that key (:421-430);
     top-k pruning (:434-449) keeps the k_keep = max(1, int(ratio * Nk)) keys of a window with the largest score (the focus
@@ -465,7 +465,10 @@ def hatx_ocab_attention(q: Tensor, k: Tensor, v: Tensor, table: Tensor, rpi: Ten
     if topk_ratio < 1.0:
         k_keep = max(1, int(topk_ratio * nk))
         score = focus_k if focus_k is not None else torch.linalg.vector_norm(kw_.transpose(1, 2), ord=2, dim=-1)
-        idx = torch.topk(score, k_keep, dim=1, sorted=False).indices
+        if tie == "torch":       # the reference: which of several equal scores survive is whatever torch.topk returns
+            idx = torch.topk(score, k_keep, dim=1, sorted=False).indices
+        else:                    # "lowest_index": the MI355X kernel's documented rule (hat_ocab_keybias): among equal scores the
+            idx = torch.argsort(-score, dim=1, stable=True)[:, :k_keep]   # key with the lower window index is kept
         keep = torch.zeros(b_, nk, dtype=torch.bool).scatter_(1, idx, True)
         attn = attn.masked_fill(~keep.view(b_, 1, 1, nk), -1e4)
     bias = table[rpi.reshape(-1)].reshape(ws * ws, wse * wse, heads).permute(2, 0, 1)
@@ -475,7 +478,7 @@ def hatx_ocab_attention(q: Tensor, k: Tensor, v: Tensor, table: Tensor, rpi: Ten
     return o.reshape(b, h, w, c)
 
 
-def hatx_ocab(t: Tensor, hw, sd: SD, p: str, rpi: Tensor, cfg: dict, heads: int) -> Tensor:
+def hatx_ocab(t: Tensor, hw, sd: SD, p: str, rpi: Tensor, cfg: dict, heads: int, tie: str = "torch") -> Tensor:
     """OCAB.forward, hatx_arch.py:367-465."""
     b, _, c = t.shape
     ws = cfg["window_size"]
@@ -494,14 +497,14 @@ def hatx_ocab(t: Tensor, hw, sd: SD, p: str, rpi: Tensor, cfg: dict, heads: int)
     if cfg["use_focus_bias"]:  # focus_head: 1x1 C -> C/4, GELU, 1x1 -> 1                      :357-361, :423
         hcw = F.gelu(F.conv2d(y_chw, sd[p + ".focus_head.0.weight"], sd[p + ".focus_head.0.bias"]))
         sal = F.conv2d(hcw, sd[p + ".focus_head.2.weight"], sd[p + ".focus_head.2.bias"])[:, 0]
-    o = hatx_ocab_attention(q, k, v, sd[p + ".relative_position_bias_table"], rpi, ws, wse, heads, scale, sal, cfg["kv_topk_ratio"])
+    o = hatx_ocab_attention(q, k, v, sd[p + ".relative_position_bias_table"], rpi, ws, wse, heads, scale, sal, cfg["kv_topk_ratio"], tie)
     t = F.linear(o.reshape(b, -1, c), sd[p + ".proj.weight"], sd[p + ".proj.bias"]) + t
     m = _ln(t, sd, p + ".norm2")
     m = F.linear(F.gelu(F.linear(m, sd[p + ".mlp.0.weight"], sd[p + ".mlp.0.bias"])), sd[p + ".mlp.2.weight"], sd[p + ".mlp.2.bias"])
     return t + m
 
 
-def hatx_forward(x: Tensor, sd: SD, cfg: dict) -> Tensor:
+def hatx_forward(x: Tensor, sd: SD, cfg: dict, tie: str = "torch") -> Tensor:
     """HATX.forward, hatx_arch.py:944-974: hat_forward with the HATX blocks."""
     if cfg["upsampler"] != "pixelshuffle":
         raise NotImplementedError("only the 'pixelshuffle' upsampler is on the hot path")
@@ -523,7 +526,7 @@ def hatx_forward(x: Tensor, sd: SD, cfg: dict) -> Tensor:
         t_in, p = t, f"layers.{g}"
         for i in range(depth):
             t = hatx_hab(t, hw, sd, f"{p}.residual_group.blocks.{i}", cfg)
-        t = hatx_ocab(t, hw, sd, f"{p}.residual_group.overlap_attn", rpi, cfg, heads)
+        t = hatx_ocab(t, hw, sd, f"{p}.residual_group.overlap_attn", rpi, cfg, heads, tie)
         if cfg["resi_connection"] == "1conv":
             t = _img2tok(F.conv2d(_tok2img(t, hw), sd[p + ".conv.weight"], sd[p + ".conv.bias"], padding=1))
         t = t + t_in

@@ -111,6 +111,8 @@ SIGNATURES = {
                                 C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p]),
     "hat_dwconv_gate": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32,
                                   C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_void_p]),
+    "hat_ocab_keybias": (C.c_int, [C.c_void_p, C.c_int32, C.c_void_p, C.c_int32, C.c_void_p] + [C.c_int32] * 9 + [C.c_void_p]),
+    "hat_ocab_attention_kb": (C.c_int, [C.c_void_p] * 5 + [C.c_int32] * 12 + [C.c_void_p]),
     "hat_sgfn_gate": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32,
                                 C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_void_p]),
     "hat_ocab_attention": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32,

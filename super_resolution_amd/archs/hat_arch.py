@@ -373,9 +373,11 @@ class HATX(HAT):
     and may prune keys (top-k).  Same constructor keywords (`hab_ffn_ratio` is accepted and, exactly like the reference,
     never used: its AttenBlocks hands `mlp_ratio` to the HABs, hatx_arch.py:513), same `state_dict()` surface.
 
-    The MI355X forward covers the SGFN and the OCAB at HATX's default options (kv_topk_ratio = 1, use_focus_bias = False,
-    even window overlap).  The focus bias and top-k pruning are restated and pinned on the CPU oracle only
-    (oracle/hat_oracle.py hatx_ocab_attention): building the engine with them raises NotImplementedError.
+    The MI355X forward covers the SGFN, the focus bias and the top-k pruning for even window overlaps with wse % 4 == 0
+    (e.g. 8 -> 12, 16 -> 24).  Among keys of EQUAL score the pruning keeps the lower window index, where the reference
+    leaves the order to torch.topk: border windows, whose zero-padded keys all score tanh(0) = 0, can therefore differ from
+    the reference; windows without padded keys cannot.  Odd overlaps (ceil padding, hatx_arch.py:303-305,
+    e.g. overlap_ratio 0.6 at window 16) raise NotImplementedError when the engine is built.
     """
     _VARIANT = "hatx"
 

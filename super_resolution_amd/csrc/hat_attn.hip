@@ -28,7 +28,7 @@ template <typename T, int NKT, int KCH, bool SELF>
 __global__ __launch_bounds__(256) void ocab_attn_kernel(const T* __restrict__ q, const T* __restrict__ kv,
                                                         const float* __restrict__ bias_rot, T* __restrict__ out, int H, int W,
                                                         int C, int heads, int ws, int wse, int ldq, int ldkv, int ldo,
-                                                        int shift) {
+                                                        int shift, const float* __restrict__ kb, int pad) {
     using M = MT<T>;
     constexpr int NK = NKT * 16;
     static_assert(NKT % KCH == 0, "key tiles must split evenly into chunks");
@@ -46,8 +46,9 @@ __global__ __launch_bounds__(256) void ocab_attn_kernel(const T* __restrict__ q,
     const int wx = blockIdx.x, wy = blockIdx.y;
     const int b = blockIdx.z / heads, h = blockIdx.z - b * heads;
     const int Mr = ws + wse - 1;
-    const int pad = (wse - ws) / 2;
     const size_t img = (size_t)b * H * W;
+    // HATX key bias / prune mask of this window (hat_ocab_keybias): NK floats, -inf = pruned key
+    const float* kbw = kb ? kb + (((size_t)b * gridDim.y + wy) * gridDim.x + wx) * NK : nullptr;
 
     for (int i = tid; i < Mr * Mr; i += 256) tab[i] = bias_rot[(size_t)h * Mr * Mr + i];
 
@@ -106,6 +107,14 @@ __global__ __launch_bounds__(256) void ocab_attn_kernel(const T* __restrict__ q,
                 // channel groups beyond dk8 are clamped: they meet a zero Q fragment, so contribute 0
                 const typename M::frag_t kf = M::load(Ks + ((kt0 + t) * 16 + c16) * ldk + (8 * g < dk8 ? 8 * g : dk8 - 8));
                 s[t] = M::mma(kf, qf, f32x4{0.f, 0.f, 0.f, 0.f});
+            }
+            if (kbw != nullptr) {   // hatx_arch.py:421-449: + focus bias per key; a pruned key's logit is REPLACED by -1e4
+#pragma unroll
+                for (int t = 0; t < KCH; ++t) {
+                    const f32x4 k4 = *reinterpret_cast<const f32x4*>(kbw + (kt0 + t) * 16 + 4 * g);
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) s[t][r] = k4[r] == -INFINITY ? -1.0e4f : s[t][r] + k4[r];
+                }
             }
             float mx = -3.0e38f;
 #pragma unroll
@@ -444,7 +453,8 @@ __global__ __launch_bounds__(256, WSE == 24 ? 2 : 4) void ocab_attn_fast_kernel(
 
 template <typename T, int NKT, int KCH, bool SELF = false>
 int launch_attn(const void* q, const void* kv, const float* bias_rot, void* out, int B, int H, int W, int C, int heads,
-                int ws, int wse, int ldq, int ldkv, int ldo, hipStream_t s, int shift = 0) {
+                int ws, int wse, int ldq, int ldkv, int ldo, hipStream_t s, int shift = 0, const float* kb = nullptr, int pad = -1) {
+    if (pad < 0) pad = (wse - ws) / 2;
     const int es = sizeof(T);
     const int Mr = ws + wse - 1;
     const int d = C / heads, dk8 = (d + 7) & ~7, dv = (d + 1) & ~1;
@@ -458,10 +468,50 @@ int launch_attn(const void* q, const void* kv, const float* bias_rot, void* out,
     }
     dim3 grid(W / ws, H / ws, B * heads);
     HAT_LAUNCH(kern, grid, dim3(256), lds, s, reinterpret_cast<const T*>(q), reinterpret_cast<const T*>(kv), bias_rot,
-                       reinterpret_cast<T*>(out), H, W, C, heads, ws, wse, ldq, ldkv, ldo, shift);
+                       reinterpret_cast<T*>(out), H, W, C, heads, ws, wse, ldq, ldkv, ldo, shift, kb, pad);
     return hat_check_launch();
 }
 
+// ---------------------------------------------------------------------------------------------------------
+// HATX key bias / prune mask (hatx_arch.py:421-449): one workgroup per key window, one thread per key.
+//   score = tanh(saliency at the key's pixel)  (0 for the zero-padded keys outside the image: tanh(0)), or ||k||_2 over all
+//   channels when there is no focus head; the k_keep keys with the largest score are kept — among EQUAL scores the key with
+//   the lower window index (torch.topk leaves that order unspecified: DESIGN.md §7) —, kb = focus score (0 without focus
+//   head) for a kept key and -inf for a pruned one.
+// ---------------------------------------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(1024) void keybias_kernel(const T* __restrict__ sal, int ldsal, const T* __restrict__ kv, int ldkv,
+                                                       float* __restrict__ kb, int H, int W, int C, int ws, int wse, int pad, int k_keep) {
+    __shared__ float sc[1024];
+    const int nk = wse * wse, key = threadIdx.x;
+    const int wx = blockIdx.x, wy = blockIdx.y, b = blockIdx.z;
+    float s = 0.f;
+    if (key < nk) {
+        const int kh = key / wse, kw = key - kh * wse;
+        const int y = wy * ws - pad + kh, x = wx * ws - pad + kw;
+        if (y >= 0 && y < H && x >= 0 && x < W) {
+            const size_t pix = ((size_t)b * H + y) * W + x;
+            if (sal != nullptr) {
+                s = tanhf(to_f(sal[pix * ldsal]));
+            } else {
+                float q = 0.f;
+                for (int c = 0; c < C; ++c) { const float v = to_f(kv[pix * ldkv + c]); q += v * v; }
+                s = sqrtf(q);
+            }
+        }
+    }
+    sc[key] = s;
+    __syncthreads();
+    if (key < nk) {
+        bool keep = true;
+        if (k_keep < nk) {
+            int rank = 0;
+            for (int j = 0; j < nk; ++j) rank += (sc[j] > s || (sc[j] == s && j < key)) ? 1 : 0;
+            keep = rank < k_keep;
+        }
+        kb[(((size_t)b * gridDim.y + wy) * gridDim.x + wx) * nk + key] = keep ? (sal != nullptr ? s : 0.f) : -INFINITY;
+    }
+}
 }  // namespace
 
 extern "C" int hat_ocab_attention(const void* q, const void* kv, const float* bias_rot, void* out, int32_t B, int32_t H,
@@ -497,6 +547,46 @@ extern "C" int hat_ocab_attention(const void* q, const void* kv, const float* bi
     }
 #undef HAT_ATTN_CASE
     return HAT_EUNSUPPORTED;  // window sizes other than 16/24 and 8/12 are not instantiated
+}
+
+extern "C" int hat_ocab_keybias(const void* sal, int32_t ldsal, const void* kv, int32_t ldkv, float* kb, int32_t B, int32_t H, int32_t W,
+                                int32_t C, int32_t ws, int32_t wse, int32_t pad, int32_t k_keep, int32_t dtype, void* stream) {
+    if (!kb || (!sal && !kv) || B < 1 || ws < 1 || H % ws || W % ws || wse < ws || wse * wse > 1024 || pad < 0 || k_keep < 1) return HAT_EINVAL;
+    if ((sal && ldsal < 1) || (!sal && ldkv < C)) return HAT_EINVAL;
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    dim3 grid(W / ws, H / ws, B);
+    if (dtype == HAT_BF16)
+        HAT_LAUNCH(keybias_kernel<bf16_t>, grid, dim3(1024), 0, s, reinterpret_cast<const bf16_t*>(sal), ldsal, reinterpret_cast<const bf16_t*>(kv), ldkv, kb,
+                   H, W, C, ws, wse, pad, k_keep);
+    else if (dtype == HAT_F32)
+        HAT_LAUNCH(keybias_kernel<float>, grid, dim3(1024), 0, s, reinterpret_cast<const float*>(sal), ldsal, reinterpret_cast<const float*>(kv), ldkv, kb, H, W,
+                   C, ws, wse, pad, k_keep);
+    else
+        return HAT_EINVAL;
+    return hat_check_launch();
+}
+
+extern "C" int hat_ocab_attention_kb(const void* q, const void* kv, const float* bias_rot, const float* kb, void* out, int32_t B, int32_t H,
+                                     int32_t W, int32_t C, int32_t heads, int32_t ws, int32_t wse, int32_t pad, int32_t ldq, int32_t ldkv,
+                                     int32_t ldo, int32_t dtype, void* stream) {
+    if (!q || !kv || !bias_rot || !kb || !out || B < 1 || heads < 1 || C % heads) return HAT_EINVAL;
+    if (ws < 4 || H % ws || W % ws || wse < ws || wse % 4 || (ws * ws) % 16 || (wse * wse) % 16 || pad != (wse - ws + 1) / 2) return HAT_EINVAL;
+    const int d = C / heads;
+    if (d > 32 || d % 2 || ldq < C || ldkv < 2 * C || ldo < C) return HAT_EINVAL;
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    const int nkt = wse * wse / 16;
+#define HAT_ATTN_CASE(TT, N, K) return launch_attn<TT, N, K>(q, kv, bias_rot, out, B, H, W, C, heads, ws, wse, ldq, ldkv, ldo, s, 0, kb, pad)
+    if (dtype == HAT_BF16) {
+        if (nkt == 36) HAT_ATTN_CASE(bf16_t, 36, 12);
+        if (nkt == 9) HAT_ATTN_CASE(bf16_t, 9, 9);
+    } else if (dtype == HAT_F32) {
+        if (nkt == 36) HAT_ATTN_CASE(float, 36, 12);
+        if (nkt == 9) HAT_ATTN_CASE(float, 9, 9);
+    } else {
+        return HAT_EINVAL;
+    }
+#undef HAT_ATTN_CASE
+    return HAT_EUNSUPPORTED;
 }
 
 extern "C" int hat_window_attention(const void* q, const void* kv, const float* bias_flip, void* out, int32_t B, int32_t H,

@@ -90,13 +90,12 @@ class HATEngine:
         self.hatx = cfg.get("variant", "hat") == "hatx"
         if self.hatx:
             # HATX (hatx_arch.py): the SGFN runs as fc1 -> hat_sgfn_gate -> fc2; the OCAB at its default options is HAT's.
-            if float(cfg.get("kv_topk_ratio", 1.0)) < 1.0 or cfg.get("use_focus_bias", False):
-                raise NotImplementedError("HATX's focus bias / top-k key pruning (hatx_arch.py:421-449) are restated on the CPU oracle "
-                                          "only (oracle.hat_oracle.hatx_ocab_attention); the MI355X path covers kv_topk_ratio=1.0, "
-                                          "use_focus_bias=False")
-            if (self.wse - self.ws) % 2:
-                raise NotImplementedError("HATX pads odd window overlaps with ceil((wse - ws) / 2) (hatx_arch.py:303-305): only even "
-                                          "overlaps (where it equals HAT's padding) are built")
+            if (self.wse - self.ws) % 2 or self.wse % 4:
+                raise NotImplementedError("HATX pads odd window overlaps with ceil((wse - ws) / 2) (hatx_arch.py:303-305); the attention "
+                                          f"kernels are built for key windows with wse % 4 == 0 and an even overlap (got ws={self.ws}, "
+                                          f"wse={self.wse})")
+        self.topk = float(cfg.get("kv_topk_ratio", 1.0)) if self.hatx else 1.0
+        self.focus = bool(cfg.get("use_focus_bias", False)) if self.hatx else False
         self.fuse_ffn = not self.hatx and ops.ffn_supported(self.C) and os.environ.get("HAT_NO_FUSED_FFN", "0") != "1"
         self._pack(state_dict)
 
@@ -197,6 +196,9 @@ class HATEngine:
             if cfg.get("ocab_esc_enable", False):
                 oc["esc"] = _ESC(sd, p + ".esc_core", p + ".esc_plk", cfg["ocab_esc_pdim"], cfg["ocab_esc_kernel"], C, dt, dev)
                 oc["esc"].aggr = self._lin(sd, *oc["esc"].aggr_keys)
+            if self.focus:  # saliency head: 1x1 C -> C/4, GELU, 1x1 -> 1                     hatx_arch.py:357-361
+                oc["fh0"] = ops.pack_conv_weight(sd[p + ".focus_head.0.weight"], sd[p + ".focus_head.0.bias"], dt, dev)
+                oc["fh2"] = ops.pack_conv_weight(sd[p + ".focus_head.2.weight"], sd[p + ".focus_head.2.bias"], dt, dev)
             L["ocab"] = oc
             L["conv"] = None if self.identity else P(f"layers.{g}.conv.weight", f"layers.{g}.conv.bias")
             self.layers.append(L)
@@ -255,6 +257,10 @@ class HATEngine:
         w["weff"] = z(B, 16, max(kpad, 64))
         if any("esc" in L["ocab"] for L in self.layers):
             w["yesc"] = z(B, N, _r8(C))
+        if self.focus:
+            w["fh"], w["sal"] = z(B, N, _r8(C // 4)), z(B, N, 8)
+        if self.focus or self.topk < 1.0:
+            w["kb"] = z(B, (H // self.ws) * (W // self.ws), self.wse * self.wse, dtype=f)
         cab2 = self.layers[0]["habs"][0]["cab2"] if self.layers and self.layers[0]["habs"] else None
         if cab2 is not None:
             tiles = ops.conv3x3_small_groups(cab2, B, H, W, self.dtype) if cab2.frag else ops.conv_tiles(cab2, H, W, self.dtype)
@@ -318,7 +324,13 @@ class HATEngine:
         with self._lock, torch.cuda.device(self.dev):
             return self._forward(x)
 
-    def _forward(self, x: torch.Tensor) -> torch.Tensor:
+    def ocab_only(self, t: torch.Tensor, group: int, H: int, W: int) -> torch.Tensor:
+        """Run only the OCAB of residual group `group` on tokens t (B, H*W, C) fp32 -> (B, H*W, C) fp32 (used by the tests)."""
+        x = torch.zeros(t.shape[0], self.cfg["in_chans"], H, W, device=self.dev)
+        with self._lock, torch.cuda.device(self.dev):
+            return self._forward(x, only_ocab=(t.to(self.dev, torch.float32).contiguous(), group))
+
+    def _forward(self, x: torch.Tensor, only_ocab=None) -> torch.Tensor:
         if x.dim() != 4 or x.shape[1] != self.cfg["in_chans"]:
             raise RuntimeError(f"expected (B,{self.cfg['in_chans']},H,W), got {tuple(x.shape)}")
         B, _, H, W = x.shape
@@ -338,10 +350,58 @@ class HATEngine:
             src, dst, gb[0], gb[1], B=B, npix=N, C_=C, ldy=(C if out_f32 else ldc), out_f32=out_f32, dtype=dt,
             gap=(w["gap"] if gap_c else None), gap_c=gap_c)
 
+        tA, tB, tC = w["tA"], w["tB"], w["tC"]
+        LNB = ops.layernorm_blocks()
+
+        def run_ocab(L, t, have_n, nblk):
+            """OCAB of residual group L on the residual stream t -> the buffer holding the result   hat_arch.py:326-393"""
+            oc = L["ocab"]
+            esc = oc.get("esc")  # OCAB                                                    :326-393
+            if not have_n:
+                ln(t, w["n"], oc["n1"], gap_c=(esc.pdim if esc else 0))
+                nblk = LNB
+            kv_src = w["n"]
+            if esc is not None:  # K/V from ESC(LN(x))                                     :336-344
+                self._esc_lk(esc, w, w["n"], B, H, W, nblk)
+                self._run_lin(esc.aggr, w["n"], w["yesc"], **geo, ldx=ldc, ldo=ldc, x0=w["y16"], c_split=esc.pdim, ldx0=16)
+                kv_src = w["yesc"]
+            s0, s1 = torch.cuda.current_stream(self.dev), self._side_stream()   # q and kv projections are independent
+            s1.wait_stream(s0)
+            with torch.cuda.stream(s1):
+                self._run_lin(oc["q"], w["n"], w["q"], **geo, ldx=ldc, ldo=ldc)
+            self._run_lin(oc["kv"], kv_src, w["kv"], **geo, ldx=ldc, ldo=w["kv"].shape[2])
+            s0.wait_stream(s1)
+            if self.focus or self.topk < 1.0:   # HATX: focus bias on the logits and / or top-k key pruning   hatx_arch.py:421-449
+                nk, pad = self.wse * self.wse, (self.wse - ws + 1) // 2
+                if self.focus:
+                    ops.conv(oc["fh0"], kv_src, w["fh"], **geo, ldx=ldc, ldo=w["fh"].shape[2], act=ACT_GELU, n_store=_r4(C // 4))
+                    ops.conv(oc["fh2"], w["fh"], w["sal"], **geo, ldx=w["fh"].shape[2], ldo=8, n_store=4)
+                k_keep = max(1, int(self.topk * nk)) if self.topk < 1.0 else nk
+                ops.ocab_keybias(w["sal"] if self.focus else None, w["kv"], w["kb"], B=B, H=H, W=W, C_=C, ws=ws, wse=self.wse, pad=pad,
+                                 k_keep=k_keep, ldsal=8, ldkv=w["kv"].shape[2], dtype=dt)
+                ops.ocab_attention_kb(w["q"], w["kv"], oc["bias_rot"], w["kb"], w["ao"], B=B, H=H, W=W, C_=C, heads=L["heads"], ws=ws,
+                                      wse=self.wse, pad=pad, ldq=ldc, ldkv=w["kv"].shape[2], ldo=ldc, dtype=dt)
+            else:
+                ops.ocab_attention(w["q"], w["kv"], oc["bias_rot"], w["ao"], B=B, H=H, W=W, C_=C, heads=L["heads"], ws=ws,
+                                   wse=self.wse, ldq=ldc, ldkv=w["kv"].shape[2], ldo=ldc, dtype=dt)
+            tout = tB if t is tA else t  # never write the RHAG input buffer
+            if oc["proj"].frag:  # norm2 (:306) rides on the projection's epilogue
+                self._run_lin(oc["proj"], w["ao"], tout, **geo, ldx=ldc, ldo=C, out_mode=O_NHWC_F32, r1=t, ldr1=C,
+                              ln=oc["n2"], ln_out=w["n"], ld_ln=ldc)
+            else:
+                self._run_lin(oc["proj"], w["ao"], tout, **geo, ldx=ldc, ldo=C, out_mode=O_NHWC_F32, r1=t, ldr1=C)
+                ln(tout, w["n"], oc["n2"])
+            self._run_lin(oc["mlp0"], w["n"], w["g"], **geo, ldx=ldc, ldo=w["g"].shape[2], act=ACT_GELU)
+            self._run_lin(oc["mlp2"], w["g"], tout, **geo, ldx=w["g"].shape[2], ldo=C, out_mode=O_NHWC_F32, r1=tout, ldr1=C)
+            return tout
+
+        if only_ocab is not None:   # test hook: one OCAB on a given residual stream (block-level parity against reference goldens)
+            t_in, gidx = only_ocab
+            w["tB"].copy_(t_in.reshape(B, N, C))
+            return run_ocab(self.layers[gidx], w["tB"], False, ops.layernorm_blocks()).clone()
         # (x - mean) * img_range ; conv_first                                           :849-853
         ops.conv(self.conv_first, x, w["f0"], **geo, ldx=0, ldo=C, x_mode=X_NCHW_F32_MEAN, out_mode=O_NHWC_F32,
                  in_scale=r, mean=mean)
-        tA, tB, tC = w["tA"], w["tB"], w["tC"]
         if self.pe_norm is not None:  # patch_embed + LN                                 :836
             ln(w["f0"], tA, self.pe_norm, out_f32=True)
         else:
@@ -351,7 +411,6 @@ class HATEngine:
                 raise RuntimeError(f"absolute_pos_embed holds {self.ape.numel() // C} positions but the input has {N} "
                                    f"pixels (ape=True fixes the input size to img_size, hat_arch.py:699-702)")
             ops.add_f32(tA, self.ape, tA, B=B, n=N * C, c_bstride=0)
-        LNB = ops.layernorm_blocks()
         for L in self.layers:
             t = tA            # current value of the residual stream (tA must survive until the RHAG tail)
             have_n = False    # w["n"] already holds the next LayerNorm of t (emitted by the fused FFN)
@@ -440,32 +499,7 @@ class HATEngine:
                                         ldo=w["g"].shape[2], dtype=dt)
                     self._run_lin(hb["fc2"], w["g"], tB, **geo, ldx=w["g"].shape[2], ldo=C, out_mode=O_NHWC_F32, r1=tB, ldr1=C)
                     t, have_n = tB, False
-            esc = oc.get("esc")  # OCAB                                                    :326-393
-            if not have_n:
-                ln(t, w["n"], oc["n1"], gap_c=(esc.pdim if esc else 0))
-                nblk = LNB
-            kv_src = w["n"]
-            if esc is not None:  # K/V from ESC(LN(x))                                     :336-344
-                self._esc_lk(esc, w, w["n"], B, H, W, nblk)
-                self._run_lin(esc.aggr, w["n"], w["yesc"], **geo, ldx=ldc, ldo=ldc, x0=w["y16"], c_split=esc.pdim, ldx0=16)
-                kv_src = w["yesc"]
-            s0, s1 = torch.cuda.current_stream(self.dev), self._side_stream()   # q and kv projections are independent
-            s1.wait_stream(s0)
-            with torch.cuda.stream(s1):
-                self._run_lin(oc["q"], w["n"], w["q"], **geo, ldx=ldc, ldo=ldc)
-            self._run_lin(oc["kv"], kv_src, w["kv"], **geo, ldx=ldc, ldo=w["kv"].shape[2])
-            s0.wait_stream(s1)
-            ops.ocab_attention(w["q"], w["kv"], oc["bias_rot"], w["ao"], B=B, H=H, W=W, C_=C, heads=L["heads"], ws=ws,
-                               wse=self.wse, ldq=ldc, ldkv=w["kv"].shape[2], ldo=ldc, dtype=dt)
-            tout = tB if t is tA else t  # never write the RHAG input buffer
-            if oc["proj"].frag:  # norm2 (:306) rides on the projection's epilogue
-                self._run_lin(oc["proj"], w["ao"], tout, **geo, ldx=ldc, ldo=C, out_mode=O_NHWC_F32, r1=t, ldr1=C,
-                              ln=oc["n2"], ln_out=w["n"], ld_ln=ldc)
-            else:
-                self._run_lin(oc["proj"], w["ao"], tout, **geo, ldx=ldc, ldo=C, out_mode=O_NHWC_F32, r1=t, ldr1=C)
-                ln(tout, w["n"], oc["n2"])
-            self._run_lin(oc["mlp0"], w["n"], w["g"], **geo, ldx=ldc, ldo=w["g"].shape[2], act=ACT_GELU)
-            self._run_lin(oc["mlp2"], w["g"], tout, **geo, ldx=w["g"].shape[2], ldo=C, out_mode=O_NHWC_F32, r1=tout, ldr1=C)
+            tout = run_ocab(L, t, have_n, nblk)
             # RHAG tail: conv3x3 + group residual, written over the group input             :556
             if L["conv"] is None:  # resi_connection == 'identity': group(x) + x                 :545-546
                 ops.add_f32(tout, tA, tA, B=B, n=N * C)

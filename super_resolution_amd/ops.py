@@ -222,6 +222,22 @@ def dwconv_gate(u, wdw, bdw, out, *, B: int, H: int, W: int, hid: int, ldu: int,
         "hat_dwconv_gate"))
 
 
+def ocab_keybias(sal, kv, kb, *, B: int, H: int, W: int, C_: int, ws: int, wse: int, pad: int, k_keep: int, ldsal: int, ldkv: int,
+                 dtype: int):
+    """HATX focus bias / top-k prune mask per (window, key) (hat_ocab_keybias)."""
+    lib = _lib.load()
+    _timed("keybias_kernel", 0.0, lambda: _lib.check(
+        lib.hat_ocab_keybias(_ptr(sal), ldsal, _ptr(kv), ldkv, _ptr(kb), B, H, W, C_, ws, wse, pad, k_keep, dtype, _stream()), "hat_ocab_keybias"))
+
+
+def ocab_attention_kb(q, kv, bias_rot, kb, out, *, B: int, H: int, W: int, C_: int, heads: int, ws: int, wse: int, pad: int, ldq: int,
+                      ldkv: int, ldo: int, dtype: int):
+    lib = _lib.load()
+    _timed(f"ocab_attn_kernel<{_TNAME[dtype]}, kb>", 2.0 * 2 * wse * wse * C_ * B * H * W, lambda: _lib.check(
+        lib.hat_ocab_attention_kb(_ptr(q), _ptr(kv), _ptr(bias_rot), _ptr(kb), _ptr(out), B, H, W, C_, heads, ws, wse, pad, ldq, ldkv, ldo,
+                                  dtype, _stream()), "hat_ocab_attention_kb"))
+
+
 def sgfn_gate(u, wdw, bdw, out, *, B: int, H: int, W: int, half: int, ldu: int, ldo: int, dtype: int):
     """HATX SGFN: out = [dw3x3(u[:half]) * silu(u[half:]) | u[half:]] (hat_sgfn_gate)."""
     lib = _lib.load()

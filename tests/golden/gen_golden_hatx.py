@@ -75,6 +75,15 @@ def main():
                 out["ocab_knorm"] = grp.overlap_attn(t, hw, rpi).numpy()
                 grp.overlap_attn.use_focus_bias = True
                 np.savez(f"{HERE}/blocks_hatx_tiny_focus_x2.npz", **out)
+                # a 48x48 map: its 4x4 interior windows see no padded key, so their top-k has no ties and the reference's
+                # output there is well defined (what the GPU kernels are held to)
+                hw2 = (48, 48)
+                t2 = synth.normal(X_SEED, "tokens48", (1, hw2[0] * hw2[1], cfg["embed_dim"]))
+                out2 = {"hw": np.array(hw2), "ocab": grp.overlap_attn(t2, hw2, rpi).numpy()}
+                grp.overlap_attn.use_focus_bias = False
+                out2["ocab_knorm"] = grp.overlap_attn(t2, hw2, rpi).numpy()
+                grp.overlap_attn.use_focus_bias = True
+                np.savez_compressed(f"{HERE}/blocks_hatx_tiny_focus_48.npz", **out2)
     with open(f"{HERE}/state_dict_surface.json", "w") as f:
         json.dump(surface, f)
     with open(f"{HERE}/meta.json", "w") as f:

@@ -63,3 +63,18 @@ def test_hatx_defaults_reduce_to_plain_attention():
     a = O.ocab_attention(q, k, v, table, rpi, 8, 12, 2, 0.3)
     b = O.hatx_ocab_attention(q, k, v, table, rpi, 8, 12, 2, 0.3)
     assert max_abs(a, b) == 0.0
+
+
+def test_hatx_interior_windows_do_not_depend_on_the_tie_rule():
+    """On the 48x48 block golden the 4x4 interior windows see no padded key: there the reference's output is the same under
+    torch.topk's tie order and under "lowest index first" (the GPU kernel's rule); border windows differ."""
+    g = golden("blocks_hatx_tiny_focus_48.npz")
+    cfg, sd = _cfg_sd("hatx_tiny_focus_x2")
+    hw = tuple(int(v) for v in g["hw"])
+    t = synth.normal(X_SEED, "tokens48", (1, hw[0] * hw[1], cfg["embed_dim"]))
+    p, rpi = "layers.0.residual_group.overlap_attn", sd["relative_position_index_OCA"]
+    for key, c in (("ocab", cfg), ("ocab_knorm", dict(cfg, use_focus_bias=False))):
+        ref = torch.from_numpy(g[key]).reshape(48, 48, -1)
+        assert max_abs(O.hatx_ocab(t, hw, sd, p, rpi, c, 2), g[key]) <= TOL
+        low = O.hatx_ocab(t, hw, sd, p, rpi, c, 2, tie="lowest_index").reshape(48, 48, -1)
+        assert max_abs(low[8:40, 8:40], ref[8:40, 8:40]) <= TOL
