@@ -328,6 +328,9 @@ typedef struct HatFfnDesc {
      * (ln_g / ln_b are ignored). */
     int32_t ldm_in;
     const void* m_in;
+    /* optional (hat_ffn2 / hat_hab_tail, with ln1_g): also write channels [0, 16) of n_out as a compact (B,H,W,16) T plane —
+     * what the next block's ESC 13x13 conv reads (32 contiguous bytes per pixel instead of 32 out of every ldn * 2) */
+    void* n16_out;
 } HatFfnDesc;
 
 int hat_ffn_tiles(const HatFfnDesc* d, int32_t* tiles_out);

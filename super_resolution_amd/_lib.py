@@ -53,7 +53,7 @@ class HatFfnDesc(C.Structure):
         ("n_out", C.c_void_p), ("gap_out", C.c_void_p),
         ("B", C.c_int32), ("H", C.c_int32), ("W", C.c_int32), ("C", C.c_int32),
         ("chunks", C.c_int32), ("ldn", C.c_int32), ("gap_c", C.c_int32), ("dtype", C.c_int32),
-        ("ldm_in", C.c_int32), ("m_in", C.c_void_p),
+        ("ldm_in", C.c_int32), ("m_in", C.c_void_p), ("n16_out", C.c_void_p),
     ]
 
 

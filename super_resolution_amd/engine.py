@@ -83,6 +83,7 @@ class HATEngine:
         self._ws_cache = collections.OrderedDict()
         self._ws_max = int(os.environ.get("HAT_WS_CACHE", "12"))
         self._ws_max_bytes = int(float(os.environ.get("HAT_WS_CACHE_GIB", "96")) * 2 ** 30)
+        self.use_n16 = os.environ.get("HAT_NO_N16") != "1"
         self._lock = threading.Lock()   # one forward at a time per engine: the workspace and side stream are shared state
         ops._lib.load()
         # fused FFN kernel (hat_ffn) for the shapes it is instantiated for; HAT_NO_FUSED_FFN=1 forces the
@@ -246,7 +247,7 @@ class HATEngine:
         w = {
             "f0": z(B, N, C, dtype=f), "tA": z(B, N, C, dtype=f), "tB": z(B, N, C, dtype=f), "tC": z(B, N, C, dtype=f),
             "n": z(B, N, _r8(C)), "n2b": z(B, N, _r8(C)), "c1": z(B, N, _r8(mid)), "c2": z(B, N, _r8(C)), "m2": z(B, N, ops.ffn_m_ld(C)),
-            "y16": z(B, N, 16), "u": z(B, N, _r8(max(hid2, 2 * C))), "g": z(B, N, _r8(max(hid2 // 2, 2 * C))),
+            "y16": z(B, N, 16), "n16": z(B, N, 16), "u": z(B, N, _r8(max(hid2, 2 * C))), "g": z(B, N, _r8(max(hid2 // 2, 2 * C))),
             "q": z(B, N, _r8(C)), "kv": z(B, N, _r8(2 * C)), "ao": z(B, N, _r8(C)),
             "fb": z(B, N, 64),
             "gap": z(B, max(ops.layernorm_blocks(), -(-H // 4) * -(-W // 16)), 16, dtype=f),
@@ -294,9 +295,11 @@ class HATEngine:
         ops.esc_weights(w["gap"], nblk, H * W, esc.w1, esc.b1, esc.w2, esc.b2, esc.plk, w["weff"], B=B,
                         pdim=esc.pdim, ksize=esc.ksize, kpad=esc.kpad, dtype=self.dtype)
 
-    def _esc_conv(self, esc: _ESC, w, n, B, H, W):
+    def _esc_conv(self, esc: _ESC, w, n, B, H, W, n16=None):
+        """n16: a compact (B,N,16) copy of n's first 16 channels when the producer wrote one (the fused HAB tail does)."""
         if ops.esc_conv13_supported(esc.pdim, esc.ksize, self.dtype) and os.environ.get("HAT_NO_ESC13") != "1":
-            ops.esc_conv13(n, w["weff"], w["y16"], B=B, H=H, W=W, ldx=_r8(self.C), kpad=esc.kpad, dtype=self.dtype)
+            src, ldx = (n16, 16) if n16 is not None else (n, _r8(self.C))
+            ops.esc_conv13(src, w["weff"], w["y16"], B=B, H=H, W=W, ldx=ldx, kpad=esc.kpad, dtype=self.dtype)
             return
         pw = ops.PackedConv(w["weff"], esc.zero_bias, esc.ksize, esc.pdim, esc.kpad, 1, 1, esc.pdim,
                             w_bstride=16 * esc.kpad)
@@ -414,13 +417,14 @@ class HATEngine:
         for L in self.layers:
             t = tA            # current value of the residual stream (tA must survive until the RHAG tail)
             have_n = False    # w["n"] already holds the next LayerNorm of t (emitted by the fused FFN)
+            have_n16 = False  # ... and w["n16"] a compact copy of its first 16 channels (fused HAB tail only)
             nblk = LNB        # number of GAP partial blocks currently in w["gap"]
             oc = L["ocab"]
             for i, hb in enumerate(L["habs"]):  # HAB                                     :217-238
                 esc = hb["esc"]
                 if not have_n:
                     ln(t, w["n"], hb["n1"], gap_c=esc.pdim)
-                    nblk = LNB
+                    nblk, have_n16 = LNB, False
                 mid = hb["cab0"].nout
                 if "fold" in hb:
                     # c2 = conv3x3(c1) never exists: its ECA pooling follows from the sums of c1 (hat_cab_fold) and the
@@ -435,7 +439,7 @@ class HATEngine:
                     self._esc_w(esc, w, B, H, W, nblk)
                     s1.wait_stream(s0)                              # n and the 13x13 weights are ready
                     with torch.cuda.stream(s1):                     # chain 2: 13x13 conv
-                        self._esc_conv(esc, w, w["n"], B, H, W)
+                        self._esc_conv(esc, w, w["n"], B, H, W, n16=(w["n16"] if have_n16 else None))
                     # chain 1: CAB squeeze conv -> fold
                     if w["sweep"]:
                         ops.cab_squeeze(w["n"], fo["sq"][0], fo["sq"][1], w["c1"], w["colsum1"], B=B, H=H, W=W, C_=C, ldx=ldc, dtype=dt)
@@ -454,9 +458,10 @@ class HATEngine:
                         tout = tB if t is not tB else tC
                         ops.hab_tail(hb["ffn"], esc.aggr, t, tout, hb["n2"][0], hb["n2"][1], n=w["n"], ldn_in=ldc, y16=w["y16"],
                                      c1=w["c1"], wf=w["wf"], bias_b=w["bias_b"], B=B, H=H, W=W, dtype=dt, ln1=nxt, n_out=w["n2b"],
-                                     ldn=ldc, gap_out=w["gap"], gap_c=gap_c)
+                                     ldn=ldc, gap_out=w["gap"], gap_c=gap_c, n16_out=(w["n16"] if self.use_n16 else None))
                         w["n"], w["n2b"] = w["n2b"], w["n"]      # the kernel reads n with a halo: its output n' is another buffer
                         t, have_n, nblk = tout, True, ops.ffn_tiles(hb["ffn"], H, W, dt)
+                        have_n16 = self.use_n16
                         continue
                     ops.aggr_cab(esc.aggr, w["n"], tB, w["c1"], w["wf"], w["bias_b"], **geo, ldx=ldc, ldo=C, x0=w["y16"],
                                  c_split=esc.pdim, ldx0=16, r1=t, ldr1=C)

@@ -464,7 +464,7 @@ def ffn_m_ld(C_: int) -> int:
     return (C_ + 1 + 31) // 32 * 32
 
 
-def _fill_ffn(d, pf: PackedFFN, t_in, t_out, ln_g, ln_b, ln1, n_out, ldn, gap_out, gap_c, m_in=None, ldm_in=0):
+def _fill_ffn(d, pf: PackedFFN, t_in, t_out, ln_g, ln_b, ln1, n_out, ldn, gap_out, gap_c, m_in=None, ldm_in=0, n16_out=None):
     d.t_in, d.t_out, d.ln_g, d.ln_b = _ptr(t_in), _ptr(t_out), _ptr(ln_g), _ptr(ln_b)
     if m_in is not None:
         d.m_in, d.ldm_in = _ptr(m_in), ldm_in
@@ -472,6 +472,7 @@ def _fill_ffn(d, pf: PackedFFN, t_in, t_out, ln_g, ln_b, ln1, n_out, ldn, gap_ou
     if ln1 is not None:
         d.ln1_g, d.ln1_b, d.n_out, d.ldn = _ptr(ln1[0]), _ptr(ln1[1]), _ptr(n_out), ldn
         d.gap_out, d.gap_c = (_ptr(gap_out) if gap_c else None), gap_c
+        d.n16_out = _ptr(n16_out)
 
 
 def ffn(pf: PackedFFN, t_in, t_out, ln_g, ln_b, *, B: int, H: int, W: int, dtype: int, ln1=None, n_out=None, ldn: int = 0,
@@ -498,14 +499,14 @@ def hab_tail_supported(pf: PackedFFN, aggr: PackedConv, mid: int, dtype: int) ->
 
 
 def hab_tail(pf: PackedFFN, aggr: PackedConv, t_in, t_out, ln_g, ln_b, *, n, ldn_in: int, y16, c1, wf, bias_b, B: int, H: int,
-             W: int, dtype: int, ln1=None, n_out=None, ldn: int = 0, gap_out=None, gap_c: int = 0):
+             W: int, dtype: int, ln1=None, n_out=None, ldn: int = 0, gap_out=None, gap_c: int = 0, n16_out=None):
     """hat_hab_tail: aggregation + folded CAB + residuals + the whole gated FFN in one launch (t_in = the residual stream
     BEFORE the aggregation)."""
     lib = _lib.load()
     h = HatHabTailDesc()
     d = h.ffn
     d.B, d.H, d.W, d.C, d.chunks, d.dtype = B, H, W, pf.C, pf.chunks, dtype
-    _fill_ffn(d, pf, t_in, t_out, ln_g, ln_b, ln1, n_out, ldn, gap_out, gap_c)
+    _fill_ffn(d, pf, t_in, t_out, ln_g, ln_b, ln1, n_out, ldn, gap_out, gap_c, n16_out=n16_out)
     h.n, h.y16, h.c1, h.w_aggr, h.wf, h.bias_b, h.ldn_in = _ptr(n), _ptr(y16), _ptr(c1), _ptr(aggr.w), _ptr(wf), _ptr(bias_b), ldn_in
     flops = B * H * W * (2.0 * pf.C * (pf.C + 72) + 2.0 * pf.C * 2 * pf.hid + 2.0 * 9 * 2 * pf.hid + 2.0 * pf.hid * pf.C)
     # algorithmic HBM bytes per pixel: n (T), y16 (T x 16), c1 (T x 8), t (fp32) read once; t_out (fp32) and the next
