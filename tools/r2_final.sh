@@ -12,6 +12,6 @@ python - <<PY
 import json
 d = json.load(open("gpurun_out/r2_final_bench.json"))
 print(d["ms_per_step"], d["value"], d["roofline"]["kernel"], d["roofline"]["frac"], d["roofline"]["traffic"], d.get("path_f32", {}).get("ms_per_frame"), d["cpu_baseline"]["value"])
-g = json.load(open("gpurun_out/r2_final_bench_g2.json"))
+g = json.loads([l for l in open("gpurun_out/r2_final_bench_g2.json") if l.startswith("{")][-1])   # gloo logs to stdout first
 print("2-rank rehearsal:", g["n_gpus"], g["scaling"], g["ms_per_step"])
 PY
