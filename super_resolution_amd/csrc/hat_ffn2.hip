@@ -312,13 +312,12 @@ __global__ __launch_bounds__(256, 2) void ffn2_kernel(const HatFfnDesc d, const 
         for (int ks = 0; ks < KS; ++ks)
             bf[ks] = __builtin_bit_cast(bf8, lds_read16(mbase + (unsigned)(i * 32 * F2_MS_ROWB + ks * 64)));
     };
-    // this lane's two Us store positions (n-tiles 2*nt2, 2*nt2+1) of its first pixel tile; tile i is 32 rows further
-    unsigned ust[2];
-#pragma unroll
-    for (int ii = 0; ii < 2; ++ii) {
-        const int nl = (2 * nt2 + ii) * 16 + 4 * g;  // chunk-local channel: [0,32) a, [32,64) gate
-        ust[ii] = lds0 + F2_US_OFF + (unsigned)hpa * F2_US_ROWB + (unsigned)(nl * 2);
-    }
+    // this lane's Us store position of its first pixel tile (tile i is 32 rows further): ONE 16-byte store holds the
+    // lane's 4 + 4 results of n-tiles 2*nt2 and 2*nt2+1, so fc1's output row (tile ii, 4g + r) is hidden unit
+    // 8g + 4ii + r of the half (ops.pack_ffn2 orders the fc1 rows that way).  Two 8-byte stores at the natural
+    // positions were 4-way bank conflicts (16 rows x 160 B = 32 (mod 128) bytes apart): 145 k of the 167 k conflict
+    // cycles per CU of the r02 profile.
+    const unsigned ust = lds0 + F2_US_OFF + (unsigned)hpa * F2_US_ROWB + (unsigned)(nt2 * 64 + g * 16);
     // bit i: pixel (tile i, column c16) of the flattened haloed tile lies inside the image
     unsigned inmask = 0;
 #pragma unroll
@@ -355,18 +354,18 @@ __global__ __launch_bounds__(256, 2) void ffn2_kernel(const HatFfnDesc d, const 
             load_b(0, bcur);
             auto store_u = [&](int i, const f32x4 (&av)[2]) {
                 if (i < F2_NPTW - 1 || hpa + 32 * i < NPH) {
+                    u32x4 pk;
 #pragma unroll
                     for (int ii = 0; ii < 2; ++ii) {
-                        u32x2 pk;
-                        pk[0] = __builtin_bit_cast(unsigned, __builtin_amdgcn_cvt_pkrtz(av[ii][0], av[ii][1]));
-                        pk[1] = __builtin_bit_cast(unsigned, __builtin_amdgcn_cvt_pkrtz(av[ii][2], av[ii][3]));
-                        if (edge) {
-                            const bool in = (inmask >> i) & 1u;
-                            pk[0] = in ? pk[0] : 0u;
-                            pk[1] = in ? pk[1] : 0u;
-                        }
-                        *(__attribute__((address_space(3))) u32x2*)(uintptr_t)(ust[ii] + (unsigned)(i * 32 * F2_US_ROWB)) = pk;
+                        pk[2 * ii] = __builtin_bit_cast(unsigned, __builtin_amdgcn_cvt_pkrtz(av[ii][0], av[ii][1]));
+                        pk[2 * ii + 1] = __builtin_bit_cast(unsigned, __builtin_amdgcn_cvt_pkrtz(av[ii][2], av[ii][3]));
                     }
+                    if (edge) {
+                        const bool in = (inmask >> i) & 1u;
+#pragma unroll
+                        for (int k = 0; k < 4; ++k) pk[k] = in ? pk[k] : 0u;
+                    }
+                    *(__attribute__((address_space(3))) u32x4*)(uintptr_t)(ust + (unsigned)(i * 32 * F2_US_ROWB)) = pk;
                 }
             };
 #pragma unroll

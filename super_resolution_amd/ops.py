@@ -415,10 +415,12 @@ def pack_ffn2(fc1_w, fc1_b, dw_w, dw_b, fc2_w, fc2_b, device) -> PackedFFN:
     chunks, ks, nt = hid // 32, 5, 9
     lane = torch.arange(64)
     n16, g4, j8 = lane & 15, lane >> 4, torch.arange(8)
-    # chunk-local channel nl in [0, 64): a-unit 32c + nl (nl < 32) or gate-unit 32c + nl - 32 -> fc1 row
+    # fc1 output row nl = tile * 16 + n16 of a chunk (tiles 0, 1: a half; 2, 3: gate half) computes hidden unit
+    # q = 8 g + 4 ii + r of its half (ii = tile & 1, n16 = 4 g + r): a lane's 4 + 4 results of the two tiles are then 16
+    # contiguous bytes of the U row, unit order natural (one conflict-free-enough ds_write_b128, hat_ffn2.hip `ust`)
     nl = torch.arange(64)
-    rows = torch.where(nl[None, :] < 32, torch.arange(chunks)[:, None] * 32 + nl[None, :],
-                       hid + torch.arange(chunks)[:, None] * 32 + nl[None, :] - 32)              # (chunks, 64)
+    q = 8 * ((nl & 15) >> 2) + 4 * ((nl >> 4) & 1) + (nl & 3)
+    rows = (nl[None, :] >> 5) * hid + torch.arange(chunks)[:, None] * 32 + q[None, :]            # (chunks, 64)
     W1p = torch.zeros(2 * hid, ks * 32)
     W1p[:, :C_] = W1
     r = rows.reshape(chunks, 4, 16)[:, :, None, n16, None].expand(chunks, 4, ks, 64, 8)
