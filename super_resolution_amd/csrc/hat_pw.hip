@@ -307,6 +307,8 @@ __global__ __launch_bounds__(WAVES * 64, MINW) void pw_kernel(const HatConvDesc 
         else if (full && f32o && d.r1 && !d.r2 && emit_ln && !d.ln_ones && ln16) tile_loop(PwTag<true, true, false, true, true, true>{});
         else if (tail_ok && f32o && d.r1 && !d.r2 && emit_ln && !d.ln_ones) tile_loop(PwTag<true, true, false, true, true, false>{});
         else if (tail_ok && f32o && d.r1 && !d.r2 && !emit_ln) tile_loop(PwTag<true, true, false, true, false>{});
+        // residual added in fp32, result stored as T rows only (the OCAB's last linear when a 3x3 conv consumes it)
+        else if (full && !f32o && d.r1 && !d.r2 && !emit_ln && out16) tile_loop(PwTag<true, true, false, false, false, true>{});
         else tile_loop(PwTag<false, false, false, false, false>{});
     } else {
         if (full && d.out_mode == HAT_O_NHWC_T && out16) tile_loop(PwTag<true, false, false, false, false, true>{});

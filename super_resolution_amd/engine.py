@@ -356,8 +356,11 @@ class HATEngine:
         tA, tB, tC = w["tA"], w["tB"], w["tC"]
         LNB = ops.layernorm_blocks()
 
-        def run_ocab(L, t, have_n, nblk):
-            """OCAB of residual group L on the residual stream t -> the buffer holding the result   hat_arch.py:326-393"""
+        def run_ocab(L, t, have_n, nblk, as_conv_input=False):
+            """OCAB of residual group L on the residual stream t -> the buffer holding the result   hat_arch.py:326-393
+            as_conv_input: the only consumer is the group's 3x3 conv, which reads its input as T (bf16) rows anyway: the last
+            linear then stores its fp32 result (+ residual) as T rows into w["n"] and the fp32 stream is not written at all
+            (same values as the conv's own staging conversion; 650 B/px less traffic per group)."""
             oc = L["ocab"]
             esc = oc.get("esc")  # OCAB                                                    :326-393
             if not have_n:
@@ -395,6 +398,9 @@ class HATEngine:
                 self._run_lin(oc["proj"], w["ao"], tout, **geo, ldx=ldc, ldo=C, out_mode=O_NHWC_F32, r1=t, ldr1=C)
                 ln(tout, w["n"], oc["n2"])
             self._run_lin(oc["mlp0"], w["n"], w["g"], **geo, ldx=ldc, ldo=w["g"].shape[2], act=ACT_GELU)
+            if as_conv_input:
+                self._run_lin(oc["mlp2"], w["g"], w["n"], **geo, ldx=w["g"].shape[2], ldo=ldc, out_mode=O_NHWC_T, r1=tout, ldr1=C)
+                return w["n"]
             self._run_lin(oc["mlp2"], w["g"], tout, **geo, ldx=w["g"].shape[2], ldo=C, out_mode=O_NHWC_F32, r1=tout, ldr1=C)
             return tout
 
@@ -504,10 +510,14 @@ class HATEngine:
                                         ldo=w["g"].shape[2], dtype=dt)
                     self._run_lin(hb["fc2"], w["g"], tB, **geo, ldx=w["g"].shape[2], ldo=C, out_mode=O_NHWC_F32, r1=tB, ldr1=C)
                     t, have_n = tB, False
-            tout = run_ocab(L, t, have_n, nblk)
+            to_conv = (L["conv"] is not None and dt == ops.HAT_BF16 and ldc == C and L["ocab"]["mlp2"].frag
+                       and not os.environ.get("HAT_NO_BF16_CONV_IN"))
+            tout = run_ocab(L, t, have_n, nblk, as_conv_input=to_conv)
             # RHAG tail: conv3x3 + group residual, written over the group input             :556
             if L["conv"] is None:  # resi_connection == 'identity': group(x) + x                 :545-546
                 ops.add_f32(tout, tA, tA, B=B, n=N * C)
+            elif to_conv:
+                ops.conv(L["conv"], tout, tA, **geo, ldx=ldc, ldo=C, x_mode=X_NHWC_T, out_mode=O_NHWC_F32, r1=tA, ldr1=C)
             else:
                 ops.conv(L["conv"], tout, tA, **geo, ldx=C, ldo=C, x_mode=X_NHWC_F32, out_mode=O_NHWC_F32, r1=tA, ldr1=C)
         # final LN; conv_after_body + f0 ; conv_before_upsample + LeakyReLU                :844, :854-855
