@@ -85,8 +85,20 @@ typedef struct HatConvDesc {
     const float* ln_g;
     const float* ln_b;
     void* ln_out;
+    /* hat_conv with ln_out (n_slices == 1, n_store == 16 nt, NHWC output, ln_ones == 0): the same fused LayerNorm in
+     * the conv's epilogue — the norm1 of the next residual group's first block, or HAT.norm, after the group conv
+     * (hat_arch.py:556 then :214 / :844) — with what the ESC path of that block needs from it:
+     * gap_out (B, hat_conv_tiles, 16) per-tile sums of the first gap_c (<= 16, % 4) LayerNorm channels over the tile's
+     * pixels (the partial sums hat_esc_weights reduces), n16_out (B,H,W,16) T a compact copy of LayerNorm channels
+     * [0,16).  Both optional (NULL). */
+    float* gap_out;
+    void* n16_out;
+    int32_t gap_c;
+    int32_t reserved0;
 } HatConvDesc;
 
+/* Debug query (not thread safe): how many workgroups of the kernel hat_conv would launch for `d` fit one CU. */
+int hat_conv_occupancy(const HatConvDesc* d, int32_t* wgs_per_cu);
 /* Number of spatial tiles hat_conv uses for (H, W, Cin, ksize, nt, dtype): the leading dimension of `colsum`. */
 int hat_conv_tiles(const HatConvDesc* d, int32_t* tiles_out);
 /* The launch plan hat_conv picks for `d`: waves per workgroup, pixel rows per wave, spatial tiles and dynamic

@@ -41,6 +41,7 @@ class HatConvDesc(C.Structure):
         ("dtype", C.c_int32),
         ("ld_ln", C.c_int32), ("ln_ones", C.c_int32),
         ("ln_g", C.c_void_p), ("ln_b", C.c_void_p), ("ln_out", C.c_void_p),
+        ("gap_out", C.c_void_p), ("n16_out", C.c_void_p), ("gap_c", C.c_int32), ("reserved0", C.c_int32),
     ]
 
 
@@ -84,6 +85,7 @@ SIGNATURES = {
     "hat_abi_version": (C.c_int, []),
     "hat_target_arch": (C.c_char_p, []),
     "hat_conv_tiles": (C.c_int, [C.POINTER(HatConvDesc), C.POINTER(C.c_int32)]),
+    "hat_conv_occupancy": (C.c_int, [C.POINTER(HatConvDesc), C.POINTER(C.c_int32)]),
     "hat_conv_plan": (C.c_int, [C.POINTER(HatConvDesc), C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.POINTER(C.c_int32),
                                 C.POINTER(C.c_int64)]),
     "hat_conv": (C.c_int, [C.POINTER(HatConvDesc), C.c_void_p]),

@@ -12,6 +12,7 @@
 //   K is flat: k = tap * Cin_p + ci; a lane's 8-element k group never straddles a tap because
 //   Cin_p % 8 == 0, so each lane tracks its own (tap, ci) and reads its B fragment from the
 //   shifted pixel: no im2col buffer exists anywhere.
+#include <cstdlib>
 #include <type_traits>
 
 #include "hat_common.h"
@@ -37,7 +38,8 @@ __host__ inline bool conv_pick(const HatConvDesc& d, TileCfg* out, size_t* lds) 
     // workgroup's load / store phases overlap the other's MFMA phase — only when the weight slice is cheap to
     // re-stream per tile (smaller tiles re-read it more often); otherwise the largest tile that fits
     const size_t wbytes = (size_t)d.nt * 16 * d.ksize * d.ksize * ((d.Cin + 7) & ~7) * es;
-    for (int pass = (wbytes <= 65536 ? 0 : 1); pass < 2; ++pass) {
+    static const bool two_wg = getenv("HAT_CONV_2WG") != nullptr;   // (experiment switch)
+    for (int pass = (wbytes <= 65536 || two_wg ? 0 : 1); pass < 2; ++pass) {
         const size_t limit = pass == 0 ? HAT_LDS_MAX / 2 : HAT_LDS_MAX;
         for (int i = 0; i < 3; ++i) {
             const int rows = cands[i].waves * cands[i].pt;
@@ -51,7 +53,7 @@ __host__ inline bool conv_pick(const HatConvDesc& d, TileCfg* out, size_t* lds) 
 }
 
 template <typename T, int WAVES, int PT, int NT>
-__global__ __launch_bounds__(WAVES * 64) void conv_kernel(const HatConvDesc d) {
+__global__ __launch_bounds__(WAVES * 64, WAVES == 4 ? 2 : 1) void conv_kernel(const HatConvDesc d) {
     using M = MT<T>;
     constexpr int NTHR = WAVES * 64;
     constexpr int TROWS = WAVES * PT;
@@ -66,6 +68,9 @@ __global__ __launch_bounds__(WAVES * 64) void conv_kernel(const HatConvDesc d) {
     constexpr int WPT = (WPIECES + NTHR - 1) / NTHR;
 
     extern __shared__ __attribute__((aligned(16))) char smem[];
+#ifdef HAT_CONV_STAMPS
+    const long long st0 = (long long)__builtin_amdgcn_s_memtime();
+#endif
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6, g = lane >> 4, c16 = lane & 15;
     const int ks_ = d.ksize;
@@ -179,6 +184,10 @@ __global__ __launch_bounds__(WAVES * 64) void conv_kernel(const HatConvDesc d) {
         }
     }
 
+#ifdef HAT_CONV_STAMPS   // tools/conv_phases.py: per-wave cycle counts of the three phases -> gap_out[wg][wave][4]
+    __syncthreads();
+    const long long st1 = (long long)__builtin_amdgcn_s_memtime();
+#endif
     const T* wg = reinterpret_cast<const T*>(d.w) + (size_t)b * d.w_bstride;
     const int nchunks = d.Kpad / KC;
     const int Npad = d.n_slices * NT * 16;
@@ -249,6 +258,9 @@ __global__ __launch_bounds__(WAVES * 64) void conv_kernel(const HatConvDesc d) {
             }
         }
 
+#ifdef HAT_CONV_STAMPS
+        const long long st2 = (long long)__builtin_amdgcn_s_memtime();
+#endif
         // ---------------------------------- epilogue ------------------------------------------
         // n-tiles are finished in groups of NG: the group's residual operands (r1, r2, r2's scale) are loaded in ONE
         // batch before any of its stores — `out` may alias r1 (in-place residual), so loads placed between the stores
@@ -291,10 +303,11 @@ __global__ __launch_bounds__(WAVES * 64) void conv_kernel(const HatConvDesc d) {
 #pragma unroll
                         for (int r = 0; r < 4; ++r) v[r] = v[r] >= 0.f ? v[r] : 0.01f * v[r];
                     }
+                    if (has_r1) v += r1v[i][pt];
+                    if (has_r2) v += scv[i] * Vec4<T>::cvt(r2v[i][pt]);
+                    acc[nt][pt] = v;   // (the fused LayerNorm below needs the finished pixel)
                     if (valid && n < d.n_store) {
                         const size_t pix = ((size_t)b * H + y) * W + x;
-                        if (has_r1) v += r1v[i][pt];
-                        if (has_r2) v += scv[i] * Vec4<T>::cvt(r2v[i][pt]);
                         if (d.out_mode == HAT_O_NHWC_T) {
                             Vec4<T>::store(reinterpret_cast<T*>(d.out) + pix * d.ldo + n, v);
                         } else if (d.out_mode == HAT_O_NHWC_F32) {
@@ -325,6 +338,76 @@ __global__ __launch_bounds__(WAVES * 64) void conv_kernel(const HatConvDesc d) {
                 }
             }
         }
+        if (d.ln_out != nullptr) {
+            // LayerNorm (eps 1e-5) of the finished pixels for the consumer of this conv's output (host checks: one slice,
+            // every channel stored): a pixel's NT*16 channels sit in the four lane groups of its column.
+            const float invC = 1.0f / (float)(NT * 16);
+            f32x4 gapv = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int pt = 0; pt < PT; ++pt) {
+                const int y = y0 + wave * PT + pt, x = x0 + c16;
+                const bool valid = (y < H) && (x < W);
+                const size_t pix = ((size_t)b * H + min(y, H - 1)) * W + min(x, W - 1);
+                float sm = 0.f;
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt) sm += (acc[nt][pt][0] + acc[nt][pt][1]) + (acc[nt][pt][2] + acc[nt][pt][3]);
+                sm += __shfl_xor(sm, 16); sm += __shfl_xor(sm, 32);
+                const float mean = sm * invC;
+                float qq = 0.f;
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) { const float dl = acc[nt][pt][r] - mean; qq += dl * dl; }
+                qq += __shfl_xor(qq, 16); qq += __shfl_xor(qq, 32);
+                const float rstd = 1.0f / sqrtf(qq * invC + 1e-5f);
+                T* lo = reinterpret_cast<T*>(d.ln_out) + pix * d.ld_ln;
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt) {
+                    const int n = nt * 16 + 4 * g;
+                    const f32x4 gm = *reinterpret_cast<const f32x4*>(d.ln_g + n);
+                    const f32x4 bt = *reinterpret_cast<const f32x4*>(d.ln_b + n);
+                    f32x4 o;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) o[r] = (acc[nt][pt][r] - mean) * rstd * gm[r] + bt[r];
+                    if (valid) {
+                        Vec4<T>::store(lo + n, o);
+                        if (nt == 0) {
+                            if (d.n16_out != nullptr) Vec4<T>::store(reinterpret_cast<T*>(d.n16_out) + pix * 16 + n, o);
+                            if (n < d.gap_c) gapv += o;
+                        }
+                    }
+                }
+            }
+            if (d.gap_out != nullptr) {
+                lds_barrier();   // (cs aliases the weight chunk: every wave is past its last read)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const float s_ = row_sum16(gapv[r]);
+                    if (c16 == 0) cs[wave * 16 + 4 * g + r] = s_;
+                }
+                __syncthreads();
+                if (tid < 16) {
+                    float s_ = 0.f;
+#pragma unroll
+                    for (int w = 0; w < WAVES; ++w) s_ += cs[w * 16 + tid];
+                    d.gap_out[((size_t)b * ntiles + tile_id) * 16 + tid] = tid < d.gap_c ? s_ : 0.f;
+                }
+                __syncthreads();
+            }
+        }
+#ifdef HAT_CONV_STAMPS
+        if (d.ln_out == nullptr && d.gap_out != nullptr) {
+            __builtin_amdgcn_s_waitcnt(0);
+            const long long st3 = (long long)__builtin_amdgcn_s_memtime();
+            if (lane == 0) {
+                float* o = d.gap_out + ((size_t)tile_id * WAVES + wave) * 8;
+                o[0] = (float)(st1 - st0); o[1] = (float)(st2 - st1); o[2] = (float)(st3 - st2); o[3] = (float)(st0 & 0xffffff);
+                o[4] = (float)(__builtin_amdgcn_s_getreg((31 << 11) | 4) & 0xffffff);    // HW_ID
+                o[5] = (float)(__builtin_amdgcn_s_getreg((31 << 11) | 20) & 0xffff);     // XCC_ID
+                o[6] = (float)((st0 >> 24) & 0xffffff);
+            }
+        }
+#endif
         if (want_cs) {
             __syncthreads();
             for (int n = tid; n < NT * 16; n += NTHR) {
@@ -338,9 +421,15 @@ __global__ __launch_bounds__(WAVES * 64) void conv_kernel(const HatConvDesc d) {
     }
 }
 
+int* g_occ_query = nullptr;   // hat_conv_occupancy: when set, launch_conv reports workgroups per CU instead of launching
+
 template <typename T, int WAVES, int PT, int NT>
 int launch_conv(const HatConvDesc& d, size_t lds, hipStream_t stream) {
     auto kern = conv_kernel<T, WAVES, PT, NT>;
+    if (g_occ_query != nullptr) {
+        if (lds > 65536) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        return (int)hipOccupancyMaxActiveBlocksPerMultiprocessor(g_occ_query, kern, WAVES * 64, lds);
+    }
     if (lds > 65536) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return (int)e;
@@ -400,6 +489,15 @@ int conv_validate(const HatConvDesc& d) {
     }
     if (d.r1 && d.ldr1 % 4) return HAT_EINVAL;
     if (d.r2 && (d.ldr2 % 4 || !d.r2scale)) return HAT_EINVAL;
+    if (d.ln_out) {   // fused LayerNorm of the output: whole pixels in one slice, NHWC rows
+        if (!d.ln_g || !d.ln_b || d.ln_ones || d.n_slices != 1 || d.n_store != d.nt * 16 || d.ld_ln % 4 || d.ld_ln < d.n_store) return HAT_EINVAL;
+        if (d.out_mode != HAT_O_NHWC_T && d.out_mode != HAT_O_NHWC_F32) return HAT_EINVAL;
+        if (d.colsum || d.gap_c < 0 || d.gap_c > 16 || d.gap_c % 4) return HAT_EINVAL;
+    } else if (d.gap_out || d.n16_out) {
+#ifndef HAT_CONV_STAMPS
+        return HAT_EINVAL;
+#endif
+    }
     return 0;
 }
 
@@ -420,6 +518,19 @@ extern "C" int hat_conv_plan(const HatConvDesc* d, int32_t* waves, int32_t* rows
     *waves = tc.waves; *rows_per_wave = tc.pt; *lds_bytes = (int64_t)lds;
     *tiles = ((d->W + 15) / 16) * ((d->H + tc.waves * tc.pt - 1) / (tc.waves * tc.pt));
     return 0;
+}
+
+/* Debug query (not thread safe): workgroups of hat_conv's kernel for `d` that fit one CU (registers, LDS). */
+extern "C" int hat_conv_occupancy(const HatConvDesc* dp, int32_t* wgs_per_cu) {
+    if (!dp || !wgs_per_cu) return HAT_EINVAL;
+    TileCfg tc; size_t lds;
+    if (!conv_pick(*dp, &tc, &lds)) return HAT_ELDS;
+    int v = 0;
+    g_occ_query = &v;
+    const int rc = dp->dtype == HAT_BF16 ? dispatch_tile<bf16_t>(*dp, tc, lds, nullptr) : dispatch_tile<float>(*dp, tc, lds, nullptr);
+    g_occ_query = nullptr;
+    *wgs_per_cu = v;
+    return rc;
 }
 
 extern "C" int hat_conv(const HatConvDesc* dp, void* stream) {

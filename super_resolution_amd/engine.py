@@ -359,7 +359,7 @@ class HATEngine:
         def run_ocab(L, t, have_n, nblk, as_conv_input=False):
             """OCAB of residual group L on the residual stream t -> the buffer holding the result   hat_arch.py:326-393
             as_conv_input: the only consumer is the group's 3x3 conv, which reads its input as T (bf16) rows anyway: the last
-            linear then stores its fp32 result (+ residual) as T rows into w["n"] and the fp32 stream is not written at all
+            linear then stores its fp32 result (+ residual) as T rows into w["ao"] and the fp32 stream is not written at all
             (same values as the conv's own staging conversion; 650 B/px less traffic per group)."""
             oc = L["ocab"]
             esc = oc.get("esc")  # OCAB                                                    :326-393
@@ -399,8 +399,8 @@ class HATEngine:
                 ln(tout, w["n"], oc["n2"])
             self._run_lin(oc["mlp0"], w["n"], w["g"], **geo, ldx=ldc, ldo=w["g"].shape[2], act=ACT_GELU)
             if as_conv_input:
-                self._run_lin(oc["mlp2"], w["g"], w["n"], **geo, ldx=w["g"].shape[2], ldo=ldc, out_mode=O_NHWC_T, r1=tout, ldr1=C)
-                return w["n"]
+                self._run_lin(oc["mlp2"], w["g"], w["ao"], **geo, ldx=w["g"].shape[2], ldo=ldc, out_mode=O_NHWC_T, r1=tout, ldr1=C)
+                return w["ao"]
             self._run_lin(oc["mlp2"], w["g"], tout, **geo, ldx=w["g"].shape[2], ldo=C, out_mode=O_NHWC_F32, r1=tout, ldr1=C)
             return tout
 
@@ -420,11 +420,16 @@ class HATEngine:
                 raise RuntimeError(f"absolute_pos_embed holds {self.ape.numel() // C} positions but the input has {N} "
                                    f"pixels (ape=True fixes the input size to img_size, hat_arch.py:699-702)")
             ops.add_f32(tA, self.ape, tA, B=B, n=N * C, c_bstride=0)
-        for L in self.layers:
+        # the group conv's epilogue emits the LayerNorm its consumer starts with (the next group's first norm1, or HAT.norm)
+        conv_ln = dt == ops.HAT_BF16 and not os.environ.get("HAT_NO_CONV_LN")
+        grp_n = grp_n16 = False   # ... so w["n"] (and w["n16"]) are already valid when a group starts
+        grp_nblk = LNB
+        for gi, L in enumerate(self.layers):
             t = tA            # current value of the residual stream (tA must survive until the RHAG tail)
-            have_n = False    # w["n"] already holds the next LayerNorm of t (emitted by the fused FFN)
-            have_n16 = False  # ... and w["n16"] a compact copy of its first 16 channels (fused HAB tail only)
-            nblk = LNB        # number of GAP partial blocks currently in w["gap"]
+            have_n = grp_n    # w["n"] already holds the next LayerNorm of t (emitted by the fused FFN / the group conv)
+            have_n16 = grp_n16  # ... and w["n16"] a compact copy of its first 16 channels
+            nblk = grp_nblk   # number of GAP partial blocks currently in w["gap"]
+            grp_n = grp_n16 = False
             oc = L["ocab"]
             for i, hb in enumerate(L["habs"]):  # HAB                                     :217-238
                 esc = hb["esc"]
@@ -516,17 +521,30 @@ class HATEngine:
             # RHAG tail: conv3x3 + group residual, written over the group input             :556
             if L["conv"] is None:  # resi_connection == 'identity': group(x) + x                 :545-546
                 ops.add_f32(tout, tA, tA, B=B, n=N * C)
-            elif to_conv:
-                ops.conv(L["conv"], tout, tA, **geo, ldx=ldc, ldo=C, x_mode=X_NHWC_T, out_mode=O_NHWC_F32, r1=tA, ldr1=C)
             else:
-                ops.conv(L["conv"], tout, tA, **geo, ldx=C, ldo=C, x_mode=X_NHWC_F32, out_mode=O_NHWC_F32, r1=tA, ldr1=C)
+                lnkw = {}
+                if conv_ln and L["conv"].n_slices == 1 and L["conv"].nout == L["conv"].nt * 16 and tout is not w["n"]:
+                    if gi + 1 < len(self.layers):
+                        nh = self.layers[gi + 1]["habs"]
+                        nxt, gap_c = (nh[0]["n1"], nh[0]["esc"].pdim) if nh else (None, 0)
+                    else:
+                        nxt, gap_c = (self.norm, 0) if self.conv_after_body is not None else (None, 0)
+                    if nxt is not None and gap_c in (0, 4, 8, 12, 16):
+                        lnkw = dict(ln=nxt, ln_out=w["n"], ld_ln=ldc, gap_out=w["gap"], gap_c=gap_c,
+                                    n16_out=(w["n16"] if self.use_n16 and gap_c else None))
+                        grp_n, grp_n16, grp_nblk = True, bool(self.use_n16 and gap_c), ops.conv_tiles(L["conv"], H, W, dt)
+                if to_conv:
+                    ops.conv(L["conv"], tout, tA, **geo, ldx=ldc, ldo=C, x_mode=X_NHWC_T, out_mode=O_NHWC_F32, r1=tA, ldr1=C, **lnkw)
+                else:
+                    ops.conv(L["conv"], tout, tA, **geo, ldx=C, ldo=C, x_mode=X_NHWC_F32, out_mode=O_NHWC_F32, r1=tA, ldr1=C, **lnkw)
         # final LN; conv_after_body + f0 ; conv_before_upsample + LeakyReLU                :844, :854-855
         if self.conv_after_body is None:   # nn.Identity: LN(t) + f0 in fp32, read as such by the next conv      :748
             ln(tA, tB, self.norm, out_f32=True)
             ops.add_f32(tB, w["f0"], tB, B=B, n=N * C)
             ops.conv(self.conv_before_up, tB, w["fb"], **geo, ldx=C, ldo=64, x_mode=X_NHWC_F32, act=ACT_LRELU)
         else:
-            ln(tA, w["n"], self.norm)
+            if not grp_n:
+                ln(tA, w["n"], self.norm)
             ops.conv(self.conv_after_body, w["n"], w["c2"], **geo, ldx=ldc, ldo=ldc, r1=w["f0"], ldr1=C)
             ops.conv(self.conv_before_up, w["c2"], w["fb"], **geo, ldx=ldc, ldo=64, act=ACT_LRELU)
         src, h, wd = w["fb"], H, W

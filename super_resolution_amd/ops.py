@@ -131,9 +131,19 @@ def conv(pw: PackedConv, x: torch.Tensor, out: torch.Tensor, *, B: int, H: int, 
          x0: Optional[torch.Tensor] = None, c_split: int = 0, ldx0: int = 0,
          r1: Optional[torch.Tensor] = None, ldr1: int = 0, r2: Optional[torch.Tensor] = None, ldr2: int = 0,
          r2scale: Optional[torch.Tensor] = None, r2scale_bstride: int = 0, colsum: Optional[torch.Tensor] = None,
-         ps_r: int = 0, in_scale: float = 1.0, out_scale: float = 1.0, mean=(0.0, 0.0, 0.0, 0.0), cin: Optional[int] = None):
+         ps_r: int = 0, in_scale: float = 1.0, out_scale: float = 1.0, mean=(0.0, 0.0, 0.0, 0.0), cin: Optional[int] = None,
+         ln=None, ln_out: Optional[torch.Tensor] = None, ld_ln: int = 0, gap_out: Optional[torch.Tensor] = None, gap_c: int = 0,
+         n16_out: Optional[torch.Tensor] = None):
+    """ln=(gamma, beta), ln_out, ld_ln: also emit LayerNorm(result) as T rows from the conv's epilogue (one slice that stores
+    every channel), with the per-tile sums of its first gap_c channels (gap_out, conv_tiles blocks) and a compact copy of
+    its first 16 channels (n16_out) for the ESC path of the block that consumes it."""
     lib = _lib.load()
     d = HatConvDesc()
+    if ln is not None:
+        d.ln_g, d.ln_b, d.ln_out, d.ld_ln = _ptr(ln[0]), _ptr(ln[1]), _ptr(ln_out), ld_ln
+    if gap_out is not None and gap_c:
+        d.gap_out, d.gap_c = _ptr(gap_out), gap_c
+    d.n16_out = _ptr(n16_out)
     d.x, d.x0, d.w, d.bias, d.out = _ptr(x), _ptr(x0), _ptr(pw.w), _ptr(pw.bias), _ptr(out)
     d.r1, d.r2, d.r2scale, d.colsum = _ptr(r1), _ptr(r2), _ptr(r2scale), _ptr(colsum)
     d.B, d.H, d.W = B, H, W

@@ -161,6 +161,43 @@ def test_conv_f32_source_inplace_residual(dtype):
 
 
 @pytest.mark.parametrize("dtype", DT)
+@pytest.mark.parametrize("geom", [(1, 32, 48, 16), (2, 19, 21, 16), (1, 16, 16, 0)], ids=["32x48", "B2_ragged_19x21", "no_gap"])
+def test_conv_group_tail_with_fused_layernorm(geom, dtype):
+    """RHAG tail with the consumer's LayerNorm in the epilogue (hat_arch.py:556 then :214): out = conv3x3(x) + r1 in place,
+    ln_out = LayerNorm(out), gap_out = per-tile sums of its first gap_c channels, n16_out = its first 16 channels."""
+    dev, ops = _dev(), _ops()
+    dt, tdt = ops.DTYPE_CODE[dtype], ops.TORCH_DTYPE[ops.DTYPE_CODE[dtype]]
+    B, H, W, gap_c = geom
+    C = 144
+    x = q(rnd("lx", (B, H, W, C)), dtype)
+    wgt = q(rnd("lw", (C, C, 3, 3), std=(9 * C) ** -0.5), dtype)
+    bias = rnd("lb", (C,), std=0.1)
+    r1 = rnd("lr", (B, H, W, C))
+    g, bt = 1.0 + rnd("lg", (C,), std=0.2), rnd("lbt", (C,), std=0.2)
+    ref = F.conv2d(x.permute(0, 3, 1, 2).double(), wgt.double(), bias.double(), padding=1).permute(0, 2, 3, 1) + r1.double()
+    ref_ln = F.layer_norm(ref, (C,), g.double(), bt.double(), 1e-5)
+    pw = ops.pack_conv_weight(wgt, bias, dt, dev)
+    xd = to_dev(x, C, tdt, dev)
+    rd = r1.reshape(B, H * W, C).to(dev).contiguous()
+    tiles = ops.conv_tiles(pw, H, W, dt)
+    n_out = torch.full((B, H * W, C), float("nan"), dtype=tdt, device=dev)
+    n16 = torch.full((B, H * W, 16), float("nan"), dtype=tdt, device=dev)
+    gap = torch.full((B, tiles, 16), float("nan"), dtype=torch.float32, device=dev)
+    ops.conv(pw, xd, rd, B=B, H=H, W=W, dtype=dt, ldx=C, ldo=C, out_mode=ops.O_NHWC_F32, r1=rd, ldr1=C,
+             ln=(g.to(dev), bt.to(dev)), ln_out=n_out, ld_ln=C, gap_out=(gap if gap_c else None), gap_c=gap_c,
+             n16_out=(n16 if gap_c else None))
+    torch.cuda.synchronize()
+    check(rd.reshape(B, H, W, C), ref, dtype, "conv + in-place residual", f32_tol=3e-5)
+    check(n_out.reshape(B, H, W, C), ref_ln, dtype, "fused LayerNorm of the conv output", f32_tol=6e-5)
+    if gap_c:
+        assert torch.equal(n16.reshape(B, H, W, 16), n_out.reshape(B, H, W, C)[..., :16]), "compact 16-channel copy"
+        got = gap.double().sum(1).cpu() / (H * W)                      # mean over pixels, as hat_esc_weights forms it
+        want = n_out.reshape(B, H * W, C)[..., :16].double().mean(1).cpu()
+        want[:, gap_c:] = 0
+        assert torch.allclose(got, want, atol=2e-3 if dtype == "bf16" else 1e-5), (got - want).abs().max()
+
+
+@pytest.mark.parametrize("dtype", DT)
 def test_conv_first_nchw_mean(dtype):
     """(x - mean) * img_range then conv_first (hat_arch.py:849-853): NCHW fp32 in, fp32 tokens out."""
     dev, ops = _dev(), _ops()
