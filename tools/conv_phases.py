@@ -46,29 +46,25 @@ for name, cin, cout, h, w_, xf32 in [("group conv 144->144 720p (bf16 in)", 144,
     e1.record()
     torch.cuda.synchronize()
     ms = e0.elapsed_time(e1) / 10
+    print(f"{name}: {ms:.3f} ms/launch", flush=True)
     run(stamps)
     torch.cuda.synchronize()
-    s = stamps.reshape(tiles, -1, 8).cpu().double()
-    nw = int((s[:, :, 0] > 0).sum(1).max())
-    s = s[:, :nw]
+    wv, pt_, tl, lds = Cc.c_int32(0), Cc.c_int32(0), Cc.c_int32(0), Cc.c_int64(0)
+    _lib.load().hat_conv_plan(Cc.byref(dd), Cc.byref(wv), Cc.byref(pt_), Cc.byref(tl), Cc.byref(lds))
+    nw = wv.value
+    s = stamps[:tiles * nw * 8].reshape(tiles, nw, 8).cpu().double()
     # timeline per CU from wave 0 of every workgroup: start (48-bit), HW_ID (cu 11:8, sh 12, se 15:13), XCC_ID
     w0 = s[:, 0]
     start = w0[:, 3] + w0[:, 6] * 2.0 ** 24
     dur = w0[:, :3].sum(1)
     hw = w0[:, 4].long()
     cu = ((hw >> 8) & 0xf) + 16 * ((hw >> 12) & 1) + 32 * ((hw >> 13) & 7) + 256 * (w0[:, 5].long() & 0xf)
+    if float(dur.max()) <= 0:
+        continue
     t0 = float(start.min())
     span = float((start + dur).max()) - t0
-    busy, gaps, ncu = 0.0, [], 0
-    for c in cu.unique():
-        m = cu == c
-        st, du = start[m] - t0, dur[m]
-        order = st.argsort()
-        st, du = st[order], du[order]
-        ncu += 1
-        busy += float(du.sum())
-        if ncu <= 2:
-            print("   cu", int(c), [(int(a), int(b)) for a, b in zip(st[:8].tolist(), du[:8].tolist())])
-    print(f"   span {span:.0f} ticks ({span / ms / 1e6:.2f} ticks/ns), {ncu} CUs seen, mean workgroups in flight per CU {busy / span / ncu:.2f}")
-    print(f"{name}: {ms:.3f} ms/launch, {tiles} tiles, {nw} waves; mean cycles (100 MHz ticks x ~24): stage {s[:,:,0].mean():.0f}  kloop {s[:,:,1].mean():.0f}  "
-          f"epilogue {s[:,:,2].mean():.0f}  (ticks)")
+    ncu = int(cu.unique().numel())
+    print(f"   {nw} waves, LDS {lds.value} B; span {span:.0f} ticks ({span / ms / 1e6:.2f} ticks/ns), {ncu} CUs seen, "
+          f"mean workgroups in flight per CU {float(dur.sum()) / span / ncu:.2f}")
+    print(f"{name}: {ms:.3f} ms/launch, {tiles} tiles; mean ticks per tile: stage {s[:,:,0].mean():.0f}  kloop {s[:,:,1].mean():.0f}  "
+          f"epilogue {s[:,:,2].mean():.0f}")
