@@ -20,7 +20,7 @@ def _cfg_sd(name):
     return cfg, synth.synth_state_dict(O.hatx_blank_state_dict(cfg), W_SEED)
 
 
-@pytest.mark.parametrize("name", ["hatx_tiny_plain_x2", "hatx_tiny_focus_x2", "hatx_train_yml"])
+@pytest.mark.parametrize("name", ["hatx_tiny_plain_x2", "hatx_tiny_focus_x2", "hatx_train_yml", "hatx_live_x2"])
 def test_hatx_state_dict_surface(name):
     """keys, ORDER, shapes, dtypes, parameter count — including the one live training config of the fork
     (options/train/train_HAT_SRx2_ESC_OCAB_from_scratch.yml:48-81: embed_dim 180, 25x25 key windows, focus head)."""
@@ -31,7 +31,7 @@ def test_hatx_state_dict_surface(name):
     assert sum(int(np.prod(s)) for k, (s, d) in spec.items() if d == torch.float32) == surf[name + ":nparams"]
 
 
-@pytest.mark.parametrize("name", ["hatx_tiny_plain_x2", "hatx_tiny_focus_x2"])
+@pytest.mark.parametrize("name", ["hatx_tiny_plain_x2", "hatx_tiny_focus_x2", "hatx_live_x2"])
 def test_hatx_whole_model(name):
     g = golden(f"whole_{name}.npz")
     cfg, sd = _cfg_sd(name)
@@ -77,4 +77,20 @@ def test_hatx_interior_windows_do_not_depend_on_the_tie_rule():
         ref = torch.from_numpy(g[key]).reshape(48, 48, -1)
         assert max_abs(O.hatx_ocab(t, hw, sd, p, rpi, c, 2), g[key]) <= TOL
         low = O.hatx_ocab(t, hw, sd, p, rpi, c, 2, tie="lowest_index").reshape(48, 48, -1)
+        assert max_abs(low[8:40, 8:40], ref[8:40, 8:40]) <= TOL
+
+
+def test_hatx_live_shapes_blocks():
+    """The shapes of the fork's live training config on a small model (tests/golden/gen_golden_hatx_live.py): ODD key window
+    (13 = 8 + int(0.7 * 8), ceil padding 3), ESC on 24 channels with a 15 x 15 kernel, OCAB-ESC on 32 channels with 17 x 17."""
+    g = golden("blocks_hatx_live_48.npz")
+    cfg, sd = _cfg_sd("hatx_live_x2")
+    hw = tuple(int(v) for v in g["hw"])
+    t = synth.normal(X_SEED, "tokens48", (1, hw[0] * hw[1], cfg["embed_dim"]))
+    p, rpi = "layers.0.residual_group", sd["relative_position_index_OCA"]
+    assert max_abs(O.hatx_hab(t, hw, sd, p + ".blocks.0", cfg), g["hab0"]) <= TOL
+    for key, c in (("ocab", cfg), ("ocab_knorm", dict(cfg, use_focus_bias=False))):
+        ref = torch.from_numpy(g[key]).reshape(48, 48, -1)
+        assert max_abs(O.hatx_ocab(t, hw, sd, p + ".overlap_attn", rpi, c, 2), g[key]) <= TOL
+        low = O.hatx_ocab(t, hw, sd, p + ".overlap_attn", rpi, c, 2, tie="lowest_index").reshape(48, 48, -1)
         assert max_abs(low[8:40, 8:40], ref[8:40, 8:40]) <= TOL
