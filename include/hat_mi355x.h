@@ -164,9 +164,9 @@ int hat_aggr_cab(const HatAggrCabDesc* d, void* stream);
 /*
  * LayerNorm over the channel dimension (eps 1e-5, affine), fp32 in -> T or fp32 out
  * (nn.LayerNorm at hat_arch.py:209,214,291,306,743 and PatchEmbed.norm :573-574).
- * Optionally emits per-block partial sums of the first `gap_c` output channels
+ * Optionally emits per-block partial sums of the first `gap_c` (<= 32, % 4) output channels
  * (the AdaptiveAvgPool2d(1) feeding the ESC dynamic kernel, esc_arch.py:96,121):
- * gap_partial[b][blk][16], blk < hat_layernorm_blocks().
+ * gap_partial[b][blk][gs], blk < hat_layernorm_blocks(), gs = 16 floats per block, 32 when gap_c > 16.
  */
 int hat_layernorm_blocks(void);
 int hat_layernorm(const float* x, void* y, const float* gamma, const float* beta, float* gap_partial,
@@ -185,6 +185,8 @@ int hat_add_f32(const float* a, const float* c, float* out, int32_t B, int64_t n
  * ESC per-sample conv weights (esc_arch.py:95-100,121-123): p = mean(gap partials);
  * dk = W2 * gelu(W1 * p + b1) + b2 (pdim*9 values); Wp[b][co][tap*Cin_p + ci] =
  * T( plk_packed[co][tap*Cin_p+ci] + (co == ci && tap in central 3x3 ? dk[co*9 + ..] : 0) ).
+ * pdim <= 32 (% 4): the GAP partial blocks are 16 floats (32 for pdim > 16, hat_layernorm's layout for gap_c = pdim) and
+ * plk_packed / w_out hold 16 rows per sample (32 for pdim > 16: two 16-row slices for hat_conv with nt = 1).
  */
 int hat_esc_weights(const float* gap_partial, int32_t nblk, int64_t npix, const float* w1, const float* b1,
                     const float* w2, const float* b2, const float* plk_packed, void* w_out, int32_t B,
@@ -215,8 +217,9 @@ int hat_dwconv_gate(const void* u, const float* wdw, const float* bdw, void* out
                     int32_t W, int32_t hid, int32_t ldu, int32_t ldo, int32_t dtype, void* stream);
 
 /*
- * HATX's OCAB options (hatx_arch.py:421-449), for window sizes the generic attention kernel is built for (wse % 4 == 0):
- *   hat_ocab_keybias      kb[b][window][key] (fp32, wse*wse per window) = tanh(sal at the key's pixel) for a kept key — 0
+ * HATX's OCAB options (hatx_arch.py:421-449), for the key windows the generic attention kernel is built for (wse = 24, 12 and
+ * the odd 25, 13):
+ *   hat_ocab_keybias      kb[b][window][key] (fp32, rows of round_up(wse*wse, 16) floats per window: whole key tiles) = tanh(sal at the key's pixel) for a kept key — 0
  *                         without a focus head (sal == NULL: the score is then ||k||_2 over the C key channels of kv) —
  *                         and -inf for a pruned one; kept = the k_keep keys of a window with the largest score, ties by
  *                         the lower key index (the reference leaves tie order to torch.topk); zero-padded keys outside

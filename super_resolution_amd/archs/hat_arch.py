@@ -373,11 +373,11 @@ class HATX(HAT):
     and may prune keys (top-k).  Same constructor keywords (`hab_ffn_ratio` is accepted and, exactly like the reference,
     never used: its AttenBlocks hands `mlp_ratio` to the HABs, hatx_arch.py:513), same `state_dict()` surface.
 
-    The MI355X forward covers the SGFN, the focus bias and the top-k pruning for even window overlaps with wse % 4 == 0
-    (e.g. 8 -> 12, 16 -> 24).  Among keys of EQUAL score the pruning keeps the lower window index, where the reference
+    The MI355X forward covers the SGFN, the focus bias and the top-k pruning for key windows of 12 / 24 (overlap 0.5) and the
+    odd 13 / 25 (ceil padding, hatx_arch.py:303-305: overlap 0.7 at window 8, 0.6 at window 16 — the live training config, in
+    bf16), ESC on up to 32 channels with kernels up to 17 x 17.  Among keys of EQUAL score the pruning keeps the lower window index, where the reference
     leaves the order to torch.topk: border windows, whose zero-padded keys all score tanh(0) = 0, can therefore differ from
-    the reference; windows without padded keys cannot.  Odd overlaps (ceil padding, hatx_arch.py:303-305,
-    e.g. overlap_ratio 0.6 at window 16) raise NotImplementedError when the engine is built.
+    the reference; windows without padded keys cannot.
     """
     _VARIANT = "hatx"
 

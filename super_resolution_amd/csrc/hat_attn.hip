@@ -24,7 +24,10 @@ template <> __device__ __forceinline__ float exp_t<bf16_t>(float x) { return __e
 // (Y, X) of the shifted frame is pixel ((Y + shift) % H, (X + shift) % W) of the map, so the two torch.roll calls become
 // addressing), and pairs whose positions fall in different bands of the shift mask (:262-280) get -100 added after the
 // bias, exactly as the reference adds its mask tensor.
-template <typename T, int NKT, int KCH, bool SELF>
+// ODD: wse % 4 != 0 (HATX: window 16, overlap 0.6 -> 25 x 25 keys).  The key window is stored as NKT * 16 >= wse * wse keys: the
+// keys past wse * wse are dead (zero K / V, logit -3e38 so that they vanish from the softmax), and a lane's four keys of a
+// tile may sit in two key rows, so each looks up its own bias entry.
+template <typename T, int NKT, int KCH, bool SELF, bool ODD = false>
 __global__ __launch_bounds__(256) void ocab_attn_kernel(const T* __restrict__ q, const T* __restrict__ kv,
                                                         const float* __restrict__ bias_rot, T* __restrict__ out, int H, int W,
                                                         int C, int heads, int ws, int wse, int ldq, int ldkv, int ldo,
@@ -63,7 +66,7 @@ __global__ __launch_bounds__(256) void ocab_attn_kernel(const T* __restrict__ q,
             x += shift; if (x >= W) x -= W;
         }
         T k0 = to_T<T>(0.f), k1 = k0, v0 = k0, v1 = k0;
-        if (c < d && y >= 0 && y < H && x >= 0 && x < W) {
+        if (c < d && (!ODD || key < wse * wse) && y >= 0 && y < H && x >= 0 && x < W) {
             const T* p = kv + (img + (size_t)y * W + x) * ldkv + h * d + c;
             k0 = p[0]; k1 = p[1];
             v0 = p[C]; v1 = p[C + 1];
@@ -122,6 +125,17 @@ __global__ __launch_bounds__(256) void ocab_attn_kernel(const T* __restrict__ q,
                 const float* tb = tab + (kh - qy + ws - 1) * Mr + (kw - qx + ws - 1);
                 // the lane's 4 keys share a mask band: shift % 4 == 0 and kw % 4 == 0
                 const float madd = (SELF && shift > 0 && 3 * band(wy * ws + kh, H) + band(wx * ws + kw, W) != rid_q) ? -100.0f : 0.0f;
+                if constexpr (ODD) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const int key = (kt0 + t) * 16 + 4 * g + r;
+                        const int khr = key / wse, kwr = key - khr * wse;
+                        const int ti = min((khr - qy + ws - 1) * Mr + (kwr - qx + ws - 1), Mr * Mr - 1);
+                        s[t][r] = key < wse * wse ? s[t][r] + tab[ti] : -3.0e38f;
+                        mx = fmaxf(mx, s[t][r]);
+                    }
+                    continue;
+                }
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     s[t][r] += tb[r];
@@ -451,17 +465,17 @@ __global__ __launch_bounds__(256, WSE == 24 ? 2 : 4) void ocab_attn_fast_kernel(
     }
 }
 
-template <typename T, int NKT, int KCH, bool SELF = false>
+template <typename T, int NKT, int KCH, bool SELF = false, bool ODD = false>
 int launch_attn(const void* q, const void* kv, const float* bias_rot, void* out, int B, int H, int W, int C, int heads,
                 int ws, int wse, int ldq, int ldkv, int ldo, hipStream_t s, int shift = 0, const float* kb = nullptr, int pad = -1) {
-    if (pad < 0) pad = (wse - ws) / 2;
+    if (pad < 0) pad = (wse - ws + 1) / 2;   // (HATX pads odd overlaps with the ceiling, hatx_arch.py:303-305)
     const int es = sizeof(T);
     const int Mr = ws + wse - 1;
     const int d = C / heads, dk8 = (d + 7) & ~7, dv = (d + 1) & ~1;
     const size_t kvb = ((size_t)NKT * 16 * lds_row_elems(dk8, es) + (size_t)dv * lds_row_elems(NKT * 16, es)) * es;
     const size_t lds = (kvb + 15) / 16 * 16 + (size_t)Mr * Mr * 4;
     if (lds > HAT_LDS_MAX) return HAT_ELDS;
-    auto kern = ocab_attn_kernel<T, NKT, KCH, SELF>;
+    auto kern = ocab_attn_kernel<T, NKT, KCH, SELF, ODD>;
     if (lds > 65536) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return (int)e;
@@ -483,7 +497,7 @@ template <typename T>
 __global__ __launch_bounds__(1024) void keybias_kernel(const T* __restrict__ sal, int ldsal, const T* __restrict__ kv, int ldkv,
                                                        float* __restrict__ kb, int H, int W, int C, int ws, int wse, int pad, int k_keep) {
     __shared__ float sc[1024];
-    const int nk = wse * wse, key = threadIdx.x;
+    const int nk = wse * wse, nkp = (nk + 15) & ~15, key = threadIdx.x;   // rows of nkp floats: the attention kernel's key tiles
     const int wx = blockIdx.x, wy = blockIdx.y, b = blockIdx.z;
     float s = 0.f;
     if (key < nk) {
@@ -509,8 +523,33 @@ __global__ __launch_bounds__(1024) void keybias_kernel(const T* __restrict__ sal
             for (int j = 0; j < nk; ++j) rank += (sc[j] > s || (sc[j] == s && j < key)) ? 1 : 0;
             keep = rank < k_keep;
         }
-        kb[(((size_t)b * gridDim.y + wy) * gridDim.x + wx) * nk + key] = keep ? (sal != nullptr ? s : 0.f) : -INFINITY;
+        kb[(((size_t)b * gridDim.y + wy) * gridDim.x + wx) * nkp + key] = keep ? (sal != nullptr ? s : 0.f) : -INFINITY;
+    } else if (key < nkp) {   // dead keys of the padded window (odd wse): the attention kernel ignores the value
+        kb[(((size_t)b * gridDim.y + wy) * gridDim.x + wx) * nkp + key] = 0.f;
     }
+}
+}  // namespace
+
+namespace {
+// The generic kernel's instantiations by key-window size: 24 / 12 (HAT: window 16 / 8, overlap 0.5), 25 (HATX training
+// config: window 16, overlap 0.6; 625 keys in 40 tiles) and 13 (window 8, overlap 0.7: the small model of the goldens).
+int attn_dispatch(const void* q, const void* kv, const float* bias_rot, void* out, int B, int H, int W, int C, int heads, int ws, int wse,
+                  int ldq, int ldkv, int ldo, int dtype, hipStream_t s, const float* kb, int pad) {
+#define HAT_ATTN_CASE(TT, N, K, ODD_) return launch_attn<TT, N, K, false, ODD_>(q, kv, bias_rot, out, B, H, W, C, heads, ws, wse, ldq, ldkv, ldo, s, 0, kb, pad)
+    if (dtype != HAT_BF16 && dtype != HAT_F32) return HAT_EINVAL;
+    if (dtype == HAT_BF16) {
+        if (wse == 24) HAT_ATTN_CASE(bf16_t, 36, 12, false);
+        if (wse == 12) HAT_ATTN_CASE(bf16_t, 9, 9, false);
+        if (wse == 25) HAT_ATTN_CASE(bf16_t, 40, 10, true);
+        if (wse == 13) HAT_ATTN_CASE(bf16_t, 11, 11, true);
+    } else {
+        if (wse == 24) HAT_ATTN_CASE(float, 36, 12, false);
+        if (wse == 12) HAT_ATTN_CASE(float, 9, 9, false);
+        if (wse == 25) HAT_ATTN_CASE(float, 40, 10, true);
+        if (wse == 13) HAT_ATTN_CASE(float, 11, 11, true);
+    }
+#undef HAT_ATTN_CASE
+    return HAT_EUNSUPPORTED;  // other key-window sizes are not instantiated
 }
 }  // namespace
 
@@ -518,7 +557,7 @@ extern "C" int hat_ocab_attention(const void* q, const void* kv, const float* bi
                                   int32_t W, int32_t C, int32_t heads, int32_t ws, int32_t wse, int32_t ldq,
                                   int32_t ldkv, int32_t ldo, int32_t dtype, void* stream) {
     if (!q || !kv || !bias_rot || !out || B < 1 || heads < 1 || C % heads) return HAT_EINVAL;
-    if (ws < 4 || H % ws || W % ws || wse < ws || (wse - ws) % 2 || wse % 4 || (ws * ws) % 16 || (wse * wse) % 16) return HAT_EINVAL;
+    if (ws < 4 || H % ws || W % ws || wse < ws || (ws * ws) % 16) return HAT_EINVAL;
     const int d = C / heads;
     if (d > 32 || d % 2 || ldq < C || ldkv < 2 * C || ldo < C) return HAT_EINVAL;
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
@@ -534,19 +573,7 @@ extern "C" int hat_ocab_attention(const void* q, const void* kv, const float* bi
                    reinterpret_cast<const bf16_t*>(kv), bias_rot, reinterpret_cast<bf16_t*>(out), B, H, W, C, heads, ldq, ldkv, ldo, 0);
         return hat_check_launch();
     }
-    const int nkt = wse * wse / 16;
-#define HAT_ATTN_CASE(TT, N, K) return launch_attn<TT, N, K>(q, kv, bias_rot, out, B, H, W, C, heads, ws, wse, ldq, ldkv, ldo, s)
-    if (dtype == HAT_BF16) {
-        if (nkt == 36) HAT_ATTN_CASE(bf16_t, 36, 12);
-        if (nkt == 9) HAT_ATTN_CASE(bf16_t, 9, 9);
-    } else if (dtype == HAT_F32) {
-        if (nkt == 36) HAT_ATTN_CASE(float, 36, 12);
-        if (nkt == 9) HAT_ATTN_CASE(float, 9, 9);
-    } else {
-        return HAT_EINVAL;
-    }
-#undef HAT_ATTN_CASE
-    return HAT_EUNSUPPORTED;  // window sizes other than 16/24 and 8/12 are not instantiated
+    return attn_dispatch(q, kv, bias_rot, out, B, H, W, C, heads, ws, wse, ldq, ldkv, ldo, dtype, s, nullptr, -1);
 }
 
 extern "C" int hat_ocab_keybias(const void* sal, int32_t ldsal, const void* kv, int32_t ldkv, float* kb, int32_t B, int32_t H, int32_t W,
@@ -570,23 +597,10 @@ extern "C" int hat_ocab_attention_kb(const void* q, const void* kv, const float*
                                      int32_t W, int32_t C, int32_t heads, int32_t ws, int32_t wse, int32_t pad, int32_t ldq, int32_t ldkv,
                                      int32_t ldo, int32_t dtype, void* stream) {
     if (!q || !kv || !bias_rot || !kb || !out || B < 1 || heads < 1 || C % heads) return HAT_EINVAL;
-    if (ws < 4 || H % ws || W % ws || wse < ws || wse % 4 || (ws * ws) % 16 || (wse * wse) % 16 || pad != (wse - ws + 1) / 2) return HAT_EINVAL;
+    if (ws < 4 || H % ws || W % ws || wse < ws || (ws * ws) % 16 || pad != (wse - ws + 1) / 2) return HAT_EINVAL;
     const int d = C / heads;
     if (d > 32 || d % 2 || ldq < C || ldkv < 2 * C || ldo < C) return HAT_EINVAL;
-    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
-    const int nkt = wse * wse / 16;
-#define HAT_ATTN_CASE(TT, N, K) return launch_attn<TT, N, K>(q, kv, bias_rot, out, B, H, W, C, heads, ws, wse, ldq, ldkv, ldo, s, 0, kb, pad)
-    if (dtype == HAT_BF16) {
-        if (nkt == 36) HAT_ATTN_CASE(bf16_t, 36, 12);
-        if (nkt == 9) HAT_ATTN_CASE(bf16_t, 9, 9);
-    } else if (dtype == HAT_F32) {
-        if (nkt == 36) HAT_ATTN_CASE(float, 36, 12);
-        if (nkt == 9) HAT_ATTN_CASE(float, 9, 9);
-    } else {
-        return HAT_EINVAL;
-    }
-#undef HAT_ATTN_CASE
-    return HAT_EUNSUPPORTED;
+    return attn_dispatch(q, kv, bias_rot, out, B, H, W, C, heads, ws, wse, ldq, ldkv, ldo, dtype, reinterpret_cast<hipStream_t>(stream), kb, pad);
 }
 
 extern "C" int hat_window_attention(const void* q, const void* kv, const float* bias_flip, void* out, int32_t B, int32_t H,

@@ -461,7 +461,7 @@ int dispatch_tile(const HatConvDesc& d, TileCfg tc, size_t lds, hipStream_t s) {
 int conv_validate(const HatConvDesc& d) {
     if (!d.x || !d.w || !d.bias || !d.out) return HAT_EINVAL;
     if (d.B < 1 || d.H < 1 || d.W < 1 || d.Cin < 1) return HAT_EINVAL;
-    if (d.ksize < 1 || (d.ksize & 1) == 0 || d.ksize > 13) return HAT_EINVAL;
+    if (d.ksize < 1 || (d.ksize & 1) == 0 || d.ksize > 17) return HAT_EINVAL;   // (17: the OCAB-ESC kernel of the HATX training config)
     if (d.dtype != HAT_F32 && d.dtype != HAT_BF16) return HAT_EINVAL;
     const int kc = (d.dtype == HAT_BF16 ? 64 : 32) * (d.nt == 1 ? 3 : (d.nt <= 4 ? 2 : 1)), vec = d.dtype == HAT_BF16 ? 8 : 4;
     const int cin_p = (d.Cin + 7) & ~7;

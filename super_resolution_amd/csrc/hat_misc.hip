@@ -5,7 +5,7 @@
 
 namespace {
 
-constexpr int LN_BLOCKS = 1024;  // fixed grid.x: the gap partial layout [B][LN_BLOCKS][16] is deterministic
+constexpr int LN_BLOCKS = 1024;  // fixed grid.x: the gap partial layout [B][LN_BLOCKS][16 or 32] is deterministic
 
 // One pixel per 16 lanes; lane j owns channels 4j + 64v (float4 each), v < NV  =>  every wave
 // instruction reads 4 pixels x 256 contiguous bytes.  Two-pass statistics in registers.
@@ -13,7 +13,7 @@ template <typename OutT, int NV>
 __global__ __launch_bounds__(256) void ln_kernel(const float* __restrict__ x, OutT* __restrict__ y,
                                                  const float* __restrict__ gamma, const float* __restrict__ beta,
                                                  float* __restrict__ gap_partial, long npix, int C, int ldy, int gap_c) {
-    __shared__ float red[16][16];
+    __shared__ float red[16][32];
     const int tid = threadIdx.x, j = tid & 15, grp = tid >> 4;
     const int b = blockIdx.y;
     const float* xb = x + (size_t)b * npix * C;
@@ -69,17 +69,19 @@ __global__ __launch_bounds__(256) void ln_kernel(const float* __restrict__ x, Ou
         }
     }
     if (gap_partial != nullptr) {
-        // lanes j < 4 hold channels 4j..4j+3 (< 16): fixed-order reduction over the 16 pixel groups
-        if (j < 4) {
+        // lanes j < 8 hold channels 4j..4j+3 (< 32): fixed-order reduction over the 16 pixel groups.  Rows of 16 floats, or of
+        // 32 when more than 16 channels are pooled (ESC on 24 / 32 channels: the HATX training config)
+        const int gs = gap_c > 16 ? 32 : 16;
+        if (j < 8) {
 #pragma unroll
             for (int r = 0; r < 4; ++r) red[grp][4 * j + r] = gsum[r];
         }
         __syncthreads();
-        if (tid < 16) {
+        if (tid < gs) {
             float s = 0.f;
 #pragma unroll
             for (int k = 0; k < 16; ++k) s += red[k][tid];
-            gap_partial[((size_t)b * gridDim.x + blockIdx.x) * 16 + tid] = tid < gap_c ? s : 0.f;
+            gap_partial[((size_t)b * gridDim.x + blockIdx.x) * gs + tid] = tid < gap_c ? s : 0.f;
         }
     }
 }
@@ -109,36 +111,38 @@ __global__ __launch_bounds__(1024) void esc_weights_kernel(const float* __restri
                                                           const float* __restrict__ w2, const float* __restrict__ b2,
                                                           const float* __restrict__ plk, T* __restrict__ w_out,
                                                           int pdim, int ksize, int Kpad) {
-    __shared__ float part[64][16];
-    __shared__ float pmean[16];
-    __shared__ float hid[8];
+    __shared__ float part[1024];
+    __shared__ float pmean[32];
+    __shared__ float hid[16];
     __shared__ float dk[9];
     const int tid = threadIdx.x, co = blockIdx.x, b = blockIdx.y;
-    if (co >= pdim) {  // rows pdim..15 of the 16-row MFMA tile are zero
-        T* z = w_out + ((size_t)b * 16 + co) * Kpad;
+    const int npad = gridDim.x;            // weight rows per sample: 16, or 32 for pdim > 16
+    const int gs = pdim > 16 ? 32 : 16;    // floats per GAP partial block (hat_layernorm's layout for gap_c = pdim)
+    if (co >= pdim) {  // rows pdim..npad-1 of the MFMA tiles are zero
+        T* z = w_out + ((size_t)b * npad + co) * Kpad;
         for (int k = tid; k < Kpad; k += 1024) z[k] = to_T<T>(0.f);
         return;
     }
-    {   // fixed-order two-level reduction of the GAP partials: 64 strided parts, 8 independent chains each, the 8 loads of
+    const int np = 1024 / gs;              // strided parts of the reduction
+    {   // fixed-order two-level reduction of the GAP partials: np strided parts, 8 independent chains each, the 8 loads of
         // an iteration unconditional (clamped + select) so that they are all in flight together — this kernel sits on the
-        // critical path in front of the 13x13 conv and is nothing but this latency
-        const int ci = tid & 15, pp = tid >> 4;
+        // critical path in front of the large-kernel conv and is nothing but this latency
+        const int ci = tid & (gs - 1), pp = tid / gs;
         float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-        const float* gp = gap_partial + (size_t)b * nblk * 16 + ci;
-        for (int k0 = pp; k0 < nblk; k0 += 512) {
+        const float* gp = gap_partial + (size_t)b * nblk * gs + ci;
+        for (int k0 = pp; k0 < nblk; k0 += np * 8) {
             float v[8];
 #pragma unroll
-            for (int u = 0; u < 8; ++u) v[u] = gp[(size_t)min(k0 + 64 * u, nblk - 1) * 16];
+            for (int u = 0; u < 8; ++u) v[u] = gp[(size_t)min(k0 + np * u, nblk - 1) * gs];
 #pragma unroll
-            for (int u = 0; u < 8; ++u) acc[u] += (k0 + 64 * u < nblk) ? v[u] : 0.f;
+            for (int u = 0; u < 8; ++u) acc[u] += (k0 + np * u < nblk) ? v[u] : 0.f;
         }
-        part[pp][ci] = ((acc[0] + acc[1]) + (acc[2] + acc[3])) + ((acc[4] + acc[5]) + (acc[6] + acc[7]));
+        part[pp * gs + ci] = ((acc[0] + acc[1]) + (acc[2] + acc[3])) + ((acc[4] + acc[5]) + (acc[6] + acc[7]));
     }
     __syncthreads();
-    if (tid < 16) {
+    if (tid < gs) {
         float s = 0.f;
-#pragma unroll
-        for (int k = 0; k < 64; ++k) s += part[k][tid];
+        for (int k = 0; k < np; ++k) s += part[k * gs + tid];
         pmean[tid] = s * inv_npix;
     }
     __syncthreads();
@@ -159,7 +163,7 @@ __global__ __launch_bounds__(1024) void esc_weights_kernel(const float* __restri
     const int cin_p = (pdim + 7) & ~7;
     const int ctr = ksize / 2;
     const float* src = plk + (size_t)co * Kpad;
-    T* dst = w_out + ((size_t)b * 16 + co) * Kpad;
+    T* dst = w_out + ((size_t)b * npad + co) * Kpad;
     for (int k = tid; k < Kpad; k += 1024) {
         float v = src[k];
         const int tap = k / cin_p, ci = k - tap * cin_p;
@@ -453,7 +457,7 @@ extern "C" int hat_layernorm(const float* x, void* y, const float* gamma, const 
                              int32_t B, int64_t npix, int32_t C, int32_t ldy, int32_t out_f32, int32_t gap_c,
                              int32_t dtype, void* stream) {
     if (!x || !y || !gamma || !beta || B < 1 || npix < 1 || C < 4 || C % 4 || C > 256 || ldy < C || ldy % 4) return HAT_EINVAL;
-    if (gap_c < 0 || gap_c > 16 || gap_c % 4 || (gap_c > 0 && !gap_partial)) return HAT_EINVAL;
+    if (gap_c < 0 || gap_c > 32 || gap_c % 4 || (gap_c > 0 && !gap_partial)) return HAT_EINVAL;
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     float* gp = gap_c > 0 ? gap_partial : nullptr;
     if (out_f32 || dtype == HAT_F32) return launch_ln<float>(x, y, gamma, beta, gp, B, npix, C, ldy, gap_c, s);
@@ -465,9 +469,9 @@ extern "C" int hat_esc_weights(const float* gap_partial, int32_t nblk, int64_t n
                                const float* w2, const float* b2, const float* plk_packed, void* w_out, int32_t B,
                                int32_t pdim, int32_t ksize, int32_t Kpad, int32_t dtype, void* stream) {
     if (!gap_partial || !w1 || !b1 || !w2 || !b2 || !plk_packed || !w_out) return HAT_EINVAL;
-    if (pdim < 2 || pdim > 16 || pdim % 4 || ksize < 3 || (ksize & 1) == 0 || B < 1 || nblk < 1) return HAT_EINVAL;
+    if (pdim < 2 || pdim > 32 || pdim % 4 || ksize < 3 || (ksize & 1) == 0 || B < 1 || nblk < 1) return HAT_EINVAL;
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
-    dim3 grid(16, B), block(1024);
+    dim3 grid(pdim > 16 ? 32 : 16, B), block(1024);
     const float inv = 1.0f / (float)npix;
     if (dtype == HAT_BF16)
         HAT_LAUNCH(esc_weights_kernel<bf16_t>, grid, block, 0, s, gap_partial, nblk, inv, w1, b1, w2, b2, plk_packed,

@@ -48,15 +48,16 @@ class _ESC:
         self.b1 = sd[core + ".plk.dwc_proj.1.bias"].detach().to(**f32).contiguous()
         self.w2 = sd[core + ".plk.dwc_proj.3.weight"].detach().reshape(pdim * 9, pdim // 2).to(**f32).contiguous()
         self.b2 = sd[core + ".plk.dwc_proj.3.bias"].detach().to(**f32).contiguous()
-        # static large-kernel filter packed in fp32 [16][Kpad]; hat_esc_weights adds the dynamic
+        # static large-kernel filter packed in fp32 [16 or 32][Kpad]; hat_esc_weights adds the dynamic
         # depthwise 3x3 on the diagonal of the central taps and casts to T per forward
         lk = ops.pack_conv_weight(sd[plk_key], None, ops.HAT_F32, dev, nt=1)
         kc = ops.KC[dtype] * 3  # nt == 1 chunk length (hat_conv.hip)
         self.kpad = -(-(ksize * ksize * _r8(pdim)) // kc) * kc
-        plk = torch.zeros(16, self.kpad, **f32)
-        plk[:, :min(self.kpad, lk.kpad)] = lk.w[:16, :min(self.kpad, lk.kpad)]
+        self.npad = 16 if pdim <= 16 else 32   # weight rows / output channels of the conv (one or two 16-row slices)
+        plk = torch.zeros(self.npad, self.kpad, **f32)
+        plk[:lk.w.shape[0], :min(self.kpad, lk.kpad)] = lk.w[:self.npad, :min(self.kpad, lk.kpad)]
         self.plk = plk.contiguous()
-        self.zero_bias = torch.zeros(16, **f32)
+        self.zero_bias = torch.zeros(self.npad, **f32)
         self.aggr = None  # packed by the engine (hat_linear when the shape is instantiated)
         self.aggr_keys = (core + ".aggr.weight", core + ".aggr.bias")
 
@@ -90,11 +91,9 @@ class HATEngine:
         # unfused kernel sequence (fc1 -> dw+gate -> fc2), kept for A/B validation of the fusion
         self.hatx = cfg.get("variant", "hat") == "hatx"
         if self.hatx:
-            # HATX (hatx_arch.py): the SGFN runs as fc1 -> hat_sgfn_gate -> fc2; the OCAB at its default options is HAT's.
-            if (self.wse - self.ws) % 2 or self.wse % 4:
-                raise NotImplementedError("HATX pads odd window overlaps with ceil((wse - ws) / 2) (hatx_arch.py:303-305); the attention "
-                                          f"kernels are built for key windows with wse % 4 == 0 and an even overlap (got ws={self.ws}, "
-                                          f"wse={self.wse})")
+            # HATX (hatx_arch.py): the SGFN runs as fc1 -> hat_sgfn_gate -> fc2; odd window overlaps are padded with
+            # ceil((wse - ws) / 2) (hatx_arch.py:303-305) and run on the generic attention kernel (key windows 25 and 13)
+            pass
         self.topk = float(cfg.get("kv_topk_ratio", 1.0)) if self.hatx else 1.0
         self.focus = bool(cfg.get("use_focus_bias", False)) if self.hatx else False
         self.fuse_ffn = not self.hatx and ops.ffn_supported(self.C) and os.environ.get("HAT_NO_FUSED_FFN", "0") != "1"
@@ -203,6 +202,10 @@ class HATEngine:
             L["ocab"] = oc
             L["conv"] = None if self.identity else P(f"layers.{g}.conv.weight", f"layers.{g}.conv.bias")
             self.layers.append(L)
+        if any(e.npad > 16 for L in self.layers for e in [hb["esc"] for hb in L["habs"]] + ([L["ocab"]["esc"]] if "esc" in L["ocab"] else [])):
+            for L in self.layers:       # the fused tail reads the ESC conv output as 16-channel rows
+                for hb in L["habs"]:
+                    hb["tail"] = False
         self.norm = (vec("norm.weight"), vec("norm.bias"))
         self.conv_after_body = None if self.identity else P("conv_after_body.weight", "conv_after_body.bias")
         self.conv_before_up = P("conv_before_upsample.0.weight", "conv_before_upsample.0.bias")
@@ -244,24 +247,26 @@ class HATEngine:
         hid2 = 2 * int(C * self.cfg["mlp_ratio"])  # fc1 width of GatedDconvFFN (hat_arch.py:99-100)
         z = lambda *shape, dtype=T: torch.zeros(*shape, dtype=dtype, device=dev)
         f = torch.float32
+        escs = [hb["esc"] for L in self.layers for hb in L["habs"]] + [L["ocab"]["esc"] for L in self.layers if "esc" in L["ocab"]]
+        yw = max([16] + [e.npad for e in escs])      # channels of the ESC conv output / floats per GAP partial block
         w = {
             "f0": z(B, N, C, dtype=f), "tA": z(B, N, C, dtype=f), "tB": z(B, N, C, dtype=f), "tC": z(B, N, C, dtype=f),
             "n": z(B, N, _r8(C)), "n2b": z(B, N, _r8(C)), "c1": z(B, N, _r8(mid)), "c2": z(B, N, _r8(C)), "m2": z(B, N, ops.ffn_m_ld(C)),
-            "y16": z(B, N, 16), "n16": z(B, N, 16), "u": z(B, N, _r8(max(hid2, 2 * C))), "g": z(B, N, _r8(max(hid2 // 2, 2 * C))),
+            "y16": z(B, N, yw), "n16": z(B, N, 16), "u": z(B, N, _r8(max(hid2, 2 * C))), "g": z(B, N, _r8(max(hid2 // 2, 2 * C))),
             "q": z(B, N, _r8(C)), "kv": z(B, N, _r8(2 * C)), "ao": z(B, N, _r8(C)),
             "fb": z(B, N, 64),
-            "gap": z(B, max(ops.layernorm_blocks(), -(-H // 4) * -(-W // 16)), 16, dtype=f),
+            "gap": z(B, max(ops.layernorm_blocks(), -(-H // 4) * -(-W // 16)), yw, dtype=f),
             "scale": z(B, 256, dtype=f), "eca_tmp": z(B, 32, 256, dtype=f),
         }
         esc0 = self.layers[0]["habs"][0]["esc"] if self.layers and self.layers[0]["habs"] else None
         kpad = max([esc0.kpad if esc0 else 0] + [L["ocab"]["esc"].kpad for L in self.layers if "esc" in L["ocab"]])
-        w["weff"] = z(B, 16, max(kpad, 64))
+        w["weff"] = z(B, yw, max(kpad, 64))
         if any("esc" in L["ocab"] for L in self.layers):
             w["yesc"] = z(B, N, _r8(C))
         if self.focus:
             w["fh"], w["sal"] = z(B, N, _r8(C // 4)), z(B, N, 8)
         if self.focus or self.topk < 1.0:
-            w["kb"] = z(B, (H // self.ws) * (W // self.ws), self.wse * self.wse, dtype=f)
+            w["kb"] = z(B, (H // self.ws) * (W // self.ws), -(-(self.wse * self.wse) // 16) * 16, dtype=f)   # rows of whole key tiles
         cab2 = self.layers[0]["habs"][0]["cab2"] if self.layers and self.layers[0]["habs"] else None
         if cab2 is not None:
             tiles = ops.conv3x3_small_groups(cab2, B, H, W, self.dtype) if cab2.frag else ops.conv_tiles(cab2, H, W, self.dtype)
@@ -301,9 +306,9 @@ class HATEngine:
             src, ldx = (n16, 16) if n16 is not None else (n, _r8(self.C))
             ops.esc_conv13(src, w["weff"], w["y16"], B=B, H=H, W=W, ldx=ldx, kpad=esc.kpad, dtype=self.dtype)
             return
-        pw = ops.PackedConv(w["weff"], esc.zero_bias, esc.ksize, esc.pdim, esc.kpad, 1, 1, esc.pdim,
-                            w_bstride=16 * esc.kpad)
-        ops.conv(pw, n, w["y16"], B=B, H=H, W=W, dtype=self.dtype, ldx=_r8(self.C), ldo=16, n_store=_r4(esc.pdim))
+        pw = ops.PackedConv(w["weff"], esc.zero_bias, esc.ksize, esc.pdim, esc.kpad, 1, esc.npad // 16, esc.pdim,
+                            w_bstride=esc.npad * esc.kpad)
+        ops.conv(pw, n, w["y16"], B=B, H=H, W=W, dtype=self.dtype, ldx=_r8(self.C), ldo=w["y16"].shape[2], n_store=_r4(esc.pdim))
 
     def _esc_lk(self, esc: _ESC, w, n, B, H, W, nblk):
         """ESC large-kernel + dynamic depthwise conv on the first pdim channels of `n` -> w['y16']."""
@@ -369,7 +374,7 @@ class HATEngine:
             kv_src = w["n"]
             if esc is not None:  # K/V from ESC(LN(x))                                     :336-344
                 self._esc_lk(esc, w, w["n"], B, H, W, nblk)
-                self._run_lin(esc.aggr, w["n"], w["yesc"], **geo, ldx=ldc, ldo=ldc, x0=w["y16"], c_split=esc.pdim, ldx0=16)
+                self._run_lin(esc.aggr, w["n"], w["yesc"], **geo, ldx=ldc, ldo=ldc, x0=w["y16"], c_split=esc.pdim, ldx0=w["y16"].shape[2])
                 kv_src = w["yesc"]
             s0, s1 = torch.cuda.current_stream(self.dev), self._side_stream()   # q and kv projections are independent
             s1.wait_stream(s0)
@@ -475,7 +480,7 @@ class HATEngine:
                         have_n16 = self.use_n16
                         continue
                     ops.aggr_cab(esc.aggr, w["n"], tB, w["c1"], w["wf"], w["bias_b"], **geo, ldx=ldc, ldo=C, x0=w["y16"],
-                                 c_split=esc.pdim, ldx0=16, r1=t, ldr1=C)
+                                 c_split=esc.pdim, ldx0=w["y16"].shape[2], r1=t, ldr1=C)
                     pre_ln = False
                 else:
                     c3 = ops.conv3x3_small if hb["cab0"].frag else ops.conv
@@ -492,7 +497,7 @@ class HATEngine:
                     pre_ln = False and "ffn" in hb and esc.aggr.frag
                     lnkw = dict(ln=hb["n2"], ln_out=w["m2"], ld_ln=w["m2"].shape[2], ln_ones=True) if pre_ln else {}
                     self._run_lin(esc.aggr, w["n"], tB, **geo, ldx=ldc, ldo=C, out_mode=O_NHWC_F32, x0=w["y16"],
-                                  c_split=esc.pdim, ldx0=16, r1=t, ldr1=C, r2=w["c2"], ldr2=ldc, r2scale=w["scale"],
+                                  c_split=esc.pdim, ldx0=w["y16"].shape[2], r1=t, ldr1=C, r2=w["c2"], ldr2=ldc, r2scale=w["scale"],
                                   r2scale_bstride=hb["cab2"].npad, **lnkw)
                 if "ffn" in hb:  # fused LN2 + fc1 + dw3x3 + gate + fc2 + residual (+ the next block's LayerNorm)
                     if i + 1 < len(L["habs"]):
@@ -500,9 +505,13 @@ class HATEngine:
                     else:
                         nxt, gap_c = oc["n1"], (oc["esc"].pdim if "esc" in oc else 0)
                     mkw = dict(m_in=w["m2"], ldm_in=w["m2"].shape[2]) if pre_ln else {}
-                    ops.ffn(hb["ffn"], tB, tC, hb["n2"][0], hb["n2"][1], B=B, H=H, W=W, dtype=dt, ln1=nxt, n_out=w["n"],
-                            ldn=ldc, gap_out=w["gap"], gap_c=gap_c, **mkw)
-                    t, have_n, nblk = tC, True, ops.ffn_tiles(hb["ffn"], H, W, dt)
+                    if gap_c > 16:   # (the fused kernels pool at most 16 channels: a wider ESC gets its LayerNorm + pool from hat_layernorm)
+                        ops.ffn(hb["ffn"], tB, tC, hb["n2"][0], hb["n2"][1], B=B, H=H, W=W, dtype=dt, **mkw)
+                        t, have_n = tC, False
+                    else:
+                        ops.ffn(hb["ffn"], tB, tC, hb["n2"][0], hb["n2"][1], B=B, H=H, W=W, dtype=dt, ln1=nxt, n_out=w["n"],
+                                ldn=ldc, gap_out=w["gap"], gap_c=gap_c, **mkw)
+                        t, have_n, nblk = tC, True, ops.ffn_tiles(hb["ffn"], H, W, dt)
                 else:
                     ln(tB, w["n"], hb["n2"])
                     hid2 = hb["fc1"].nout

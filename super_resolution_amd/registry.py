@@ -64,4 +64,5 @@ def build_network(opt: dict):
     """`basicsr.archs.build_network` (archs/__init__.py:18-24): pop 'type', instantiate from the registry."""
     opt = dict(opt)
     network_type = opt.pop('type')
+    from . import archs  # noqa: F401  (registers HAT / HATX, as basicsr's arch scan does on import)
     return ARCH_REGISTRY.get(network_type)(**opt)

@@ -79,8 +79,8 @@ def test_hatx_default_options_vs_reference_golden(dtype):
 
 
 def test_hatx_sgfn_c144_vs_oracle_and_unbuilt_options_fail_loudly():
-    """HATX at embed_dim 144 (SGFN 144 -> 288 -> [144 | 144] -> 144 on the tuned linears) against the CPU oracle; an odd
-    window overlap (ceil padding, 25x25 key windows: not built) raises instead of silently running something else."""
+    """HATX at embed_dim 144 (SGFN 144 -> 288 -> [144 | 144] -> 144 on the tuned linears) against the CPU oracle; a key window
+    no attention kernel is instantiated for raises instead of silently running something else."""
     dev = _dev()
     from super_resolution_amd.registry import build_network
     kw = dict(META["cfgs"]["hats_1g_x4"], depths=[2], upscale=2)
@@ -93,8 +93,8 @@ def test_hatx_sgfn_c144_vs_oracle_and_unbuilt_options_fail_loudly():
     y = net.to(dev)(x.to(dev))
     torch.cuda.synchronize()
     assert_close(y, ref, "bf16", "HATX C=144 vs oracle")
-    bad = build_network(dict(type="HATX", **dict(kw, overlap_ratio=0.6))).eval().to(dev)     # 16 -> 25
-    with pytest.raises(NotImplementedError):
+    bad = build_network(dict(type="HATX", **dict(kw, overlap_ratio=0.8))).eval().to(dev)     # 16 -> 28: no kernel for that window
+    with pytest.raises(RuntimeError):
         bad(torch.rand(1, 3, 32, 32, device=dev))
 
 
@@ -149,6 +149,80 @@ def test_hatx_ocab_interior_windows_vs_reference_golden(mode):
     got = out.reshape(48, 48, 24).cpu()
     err = float((got[8:40, 8:40] - ref[8:40, 8:40]).abs().max())
     assert err <= 1e-4, f"interior windows vs reference: {err:.3e}"
+
+
+@pytest.mark.parametrize("dtype", ["f32", "bf16"])
+def test_hatx_live_shapes_whole_model(dtype):
+    """The SHAPES of the fork's live HATX training config on a small model (tests/golden/gen_golden_hatx_live.py): odd key
+    window (13 x 13, ceil padding; the 25 x 25 of the real config runs the same kernel template), ESC on 24 channels with a
+    15 x 15 kernel, OCAB-ESC on 32 channels with 17 x 17, SGFN ratio 3, focus bias + top-k.  Whole model against the CPU
+    oracle with the kernel's tie rule (every window of the 16 x 24 frame sees padded keys)."""
+    dev = _dev()
+    from super_resolution_amd.registry import build_network
+    name = "hatx_live_x2"
+    cfg = O.make_hatx_cfg(**META["cfgs"][name])
+    sd = synth.synth_state_dict(O.hatx_blank_state_dict(cfg), W_SEED)
+    x = synth.synth_input(X_SEED, (1, 3, 16, 24))
+    ref = O.hatx_forward(x, sd, cfg, tie="lowest_index")
+    net = build_network(dict(type="HATX", compute_dtype=dtype, **META["cfgs"][name])).eval()
+    net.load_state_dict(sd, strict=True)
+    y = net.to(dev)(x.to(dev))
+    torch.cuda.synchronize()
+    if dtype == "f32":
+        assert_close(y, ref, dtype, "HATX live shapes vs oracle (lowest-index ties)")
+    else:
+        yc = y.float().cpu()
+        assert torch.isfinite(yc).all() and O.psnr_float(yc, ref) >= 35.0
+
+
+def test_hatx_live_config_dimensions_bf16_vs_oracle():
+    """The fork's live training config itself (options/train/train_HAT_SRx2_ESC_OCAB_from_scratch.yml:48-81: embed_dim 180,
+    window 16 with 25 x 25 key windows, six heads of 30, ESC 24 / 15 and OCAB-ESC 32 / 17, focus bias + top-k 0.6) cut to two
+    groups of one block, bf16, against the CPU oracle with the kernel's tie rule.  (The exact-fp32 path has no room for a
+    25 x 25 key window of 30-channel heads in LDS and says so.)"""
+    dev = _dev()
+    from super_resolution_amd.registry import build_network
+    kw = dict(META["cfgs"]["hatx_train_yml"], depths=[1, 1], num_heads=[6, 6])
+    cfg = O.make_hatx_cfg(**kw)
+    sd = synth.synth_state_dict(O.hatx_blank_state_dict(cfg), W_SEED)
+    x = synth.synth_input(X_SEED, (1, 3, 32, 48))
+    ref = O.hatx_forward(x, sd, cfg, tie="lowest_index")
+    net = build_network(dict(type="HATX", compute_dtype="bf16", **kw)).eval()
+    net.load_state_dict(sd, strict=True)
+    y = net.to(dev)(x.to(dev))
+    torch.cuda.synchronize()
+    yc = y.float().cpu()
+    assert torch.isfinite(yc).all() and O.psnr_float(yc, ref) >= 35.0, O.psnr_float(yc, ref)
+    net32 = build_network(dict(type="HATX", compute_dtype="f32", **kw)).eval()
+    net32.load_state_dict(sd, strict=True)
+    with pytest.raises(RuntimeError):
+        net32.to(dev)(x.to(dev))
+
+
+@pytest.mark.parametrize("mode", ["focus", "knorm"])
+def test_hatx_live_shapes_ocab_interior_windows_vs_reference_golden(mode):
+    """The OCAB of the live-shape config (13 x 13 keys, OCAB-ESC 32 / 17) on a 48 x 48 map against the REFERENCE's own output on
+    the interior windows (no padded key, no top-k ties), fp32 path."""
+    dev = _dev()
+    from super_resolution_amd.engine import HATEngine
+    from super_resolution_amd.registry import build_network
+    name = "hatx_live_x2"
+    g = golden("blocks_hatx_live_48.npz")
+    ocfg = O.make_hatx_cfg(**META["cfgs"][name])
+    sd = synth.synth_state_dict(O.hatx_blank_state_dict(ocfg), W_SEED)
+    net = build_network(dict(type="HATX", compute_dtype="f32", **META["cfgs"][name])).eval()
+    net.load_state_dict(sd, strict=True)
+    net = net.to(dev)
+    net.cfg["use_focus_bias"] = mode == "focus"
+    eng = HATEngine(net.cfg, net.state_dict(), dev, "f32")
+    hw, C = (48, 48), ocfg["embed_dim"]
+    t = synth.normal(X_SEED, "tokens48", (1, hw[0] * hw[1], C)).to(dev)
+    out = eng.ocab_only(t, 0, *hw)
+    torch.cuda.synchronize()
+    ref = torch.from_numpy(g["ocab" if mode == "focus" else "ocab_knorm"]).reshape(48, 48, C)
+    got = out.reshape(48, 48, C).cpu()
+    err = float((got[8:40, 8:40] - ref[8:40, 8:40]).abs().max())
+    assert err <= 2e-4, f"interior windows vs reference: {err:.3e}"
 
 
 @pytest.mark.parametrize("dtype", ["f32", "bf16"])

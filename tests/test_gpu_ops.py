@@ -261,8 +261,8 @@ def test_layernorm(dtype, C):
     ref = F.layer_norm(x.double(), (C,), gm.double(), bt.double(), 1e-5)
     ld = _r8(C)
     y = torch.zeros(B, N, ld, dtype=tdt, device=dev)
-    gap = torch.zeros(B, ops.layernorm_blocks(), 16, device=dev)
-    gap_c = 16 if C >= 16 else 8
+    gap_c = {24: 8, 144: 16, 180: 24}[C]   # 24: more than 16 pooled channels -> blocks of 32 floats (wide ESC of HATX)
+    gap = torch.zeros(B, ops.layernorm_blocks(), 32 if gap_c > 16 else 16, device=dev)
     ops.layernorm(x.to(dev), y, gm.to(dev), bt.to(dev), B=B, npix=N, C_=C, ldy=ld, out_f32=False, dtype=dt, gap=gap, gap_c=gap_c)
     yf = torch.zeros(B, N, C, device=dev)
     ops.layernorm(x.to(dev), yf, gm.to(dev), bt.to(dev), B=B, npix=N, C_=C, ldy=C, out_f32=True, dtype=dt)
@@ -291,21 +291,25 @@ def test_dwconv_gate(dtype):
 
 
 @pytest.mark.parametrize("dtype", DT)
-@pytest.mark.parametrize("geom", [(16, 6, 144, 32, 48), (16, 6, 180, 32, 16), (8, 2, 24, 16, 24)],
-                         ids=["ws16_d24", "ws16_d30", "ws8_d12"])
+@pytest.mark.parametrize("geom", [(16, 6, 144, 32, 48, 0.5), (16, 6, 180, 32, 16, 0.5), (8, 2, 24, 16, 24, 0.5), (8, 2, 48, 16, 24, 0.7),
+                                  (16, 6, 144, 32, 32, 0.6)],
+                         ids=["ws16_d24", "ws16_d30", "ws8_d12", "ws8_odd13_d24", "ws16_odd25_d24"])
 def test_ocab_attention(dtype, geom):
-    ws, heads, C, H, W = geom
+    """hat_ocab_attention against the oracle's attention core; the last two geometries have ODD key windows (HATX: ceil
+    padding, hatx_arch.py:303-305; key tiles padded with dead keys)."""
+    ws, heads, C, H, W, ov = geom
     dev, ops = _dev(), _ops()
     dt = ops.DTYPE_CODE[dtype]
     tdt = ops.TORCH_DTYPE[dt]
     B = 2
-    wse = ws + ws // 2
+    wse = int(ws * ov) + ws
     d = C // heads
     qv = q(rnd("aq", (B, H, W, C)) * d ** -0.5, dtype)
     kv = q(rnd("akv", (B, H, W, 2 * C)), dtype)
     table = rnd("atab", ((ws + wse - 1) ** 2, heads), std=0.5)
-    rpi = O.rpi_oca(ws, 0.5)
-    ref = O.ocab_attention(qv.double(), kv[..., :C].double(), kv[..., C:].double(), table.double(), rpi, ws, wse, heads, 1.0)
+    rpi = O.rpi_oca(ws, ov)
+    attn = O.hatx_ocab_attention if wse % 2 else O.ocab_attention     # (identical for even overlaps; HATX's pads odd ones)
+    ref = attn(qv.double(), kv[..., :C].double(), kv[..., C:].double(), table.double(), rpi, ws, wse, heads, 1.0)
     M = ws + wse - 1
     shift = (ws - wse + 1 - (ws - 1)) * (M + 1)
     rot = (torch.arange(M * M) + shift) % (M * M)
@@ -337,13 +341,14 @@ def test_ocab_attention_softmax_spike():
 
 
 @pytest.mark.parametrize("dtype", DT)
-@pytest.mark.parametrize("pdim,ks", [(16, 13), (8, 5)])
+@pytest.mark.parametrize("pdim,ks", [(16, 13), (8, 5), (24, 15), (32, 17)])
 def test_esc_weights_and_eca(dtype, pdim, ks):
     dev, ops = _dev(), _ops()
     dt = ops.DTYPE_CODE[dtype]
     tdt = ops.TORCH_DTYPE[dt]
     B, N, nblk = 2, 777, ops.layernorm_blocks()
-    gap = rnd("gp", (B, nblk, 16), std=1.0)
+    npad = 16 if pdim <= 16 else 32   # weight rows per sample and floats per GAP block
+    gap = rnd("gp", (B, nblk, npad), std=1.0)
     gap[:, :, pdim:] = 0
     w1, b1 = rnd("w1", (pdim // 2, pdim), std=0.3), rnd("b1", (pdim // 2,), std=0.1)
     w2, b2 = rnd("w2", (pdim * 9, pdim // 2), std=0.3), rnd("b2", (pdim * 9,), std=0.1)
@@ -358,16 +363,16 @@ def test_esc_weights_and_eca(dtype, pdim, ks):
     lk = ops.pack_conv_weight(plk, None, ops.HAT_F32, dev, nt=1)
     kc = ops.KC[dt] * 3
     kpad = -(-(ks * ks * _r8(pdim)) // kc) * kc
-    plkp = torch.zeros(16, kpad, device=dev)
-    plkp[:, :min(kpad, lk.kpad)] = lk.w[:16, :min(kpad, lk.kpad)]
-    wout = torch.full((B, 16, kpad), 7.0, dtype=tdt, device=dev)
+    plkp = torch.zeros(npad, kpad, device=dev)
+    plkp[:lk.w.shape[0], :min(kpad, lk.kpad)] = lk.w[:npad, :min(kpad, lk.kpad)]
+    wout = torch.full((B, npad, kpad), 7.0, dtype=tdt, device=dev)
     ops.esc_weights(gap.to(dev), nblk, N, w1.to(dev), b1.to(dev), w2.to(dev), b2.to(dev), plkp, wout, B=B, pdim=pdim, ksize=ks,
                     kpad=kpad, dtype=dt)
     torch.cuda.synchronize()
     cin_p = _r8(pdim)
     got = wout.float().cpu()[:, :pdim, :ks * ks * cin_p].reshape(B, pdim, ks, ks, cin_p)[..., :pdim].permute(0, 1, 4, 2, 3)
     check(got, weff, dtype, "esc weights", f32_tol=1e-5)
-    assert float(wout[:, pdim:].float().abs().max()) == 0.0 if pdim < 16 else True
+    assert float(wout[:, pdim:].float().abs().max()) == 0.0 if pdim < npad else True
     # ECA
     C, tiles, ldc = 144, 37, 144
     cs = rnd("cs", (B, tiles, ldc), std=3.0)
