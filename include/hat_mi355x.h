@@ -250,6 +250,9 @@ int hat_sgfn_gate(const void* u, const float* wdw, const float* bdw, void* out, 
  * rotated so that index (kh-qh+ws-1)*(ws+wse-1) + (kw-qw+ws-1) is non-negative (the reference's
  * negative-index wraparound, hat_arch.py:378, is applied when the table is packed).
  * out: (B,H,W,ldo) T in window_reverse order (:387-388).
+ * Key windows: wse = 24 and 12 (window 16 / 8, overlap 0.5; padding (wse - ws) / 2 on every side) and the odd 25 and 13
+ * (HATX: overlap 0.6 / 0.7, padding ceil((wse - ws) / 2), hatx_arch.py:303-305); HAT_EUNSUPPORTED for others, HAT_ELDS when
+ * K and V of one key window do not fit the LDS (fp32, wse 25, head_dim 30).
  */
 int hat_ocab_attention(const void* q, const void* kv, const float* bias_rot, void* out, int32_t B, int32_t H,
                        int32_t W, int32_t C, int32_t heads, int32_t ws, int32_t wse, int32_t ldq,
