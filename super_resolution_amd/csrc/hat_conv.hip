@@ -17,6 +17,10 @@
 
 #include "hat_common.h"
 
+// hat_conv64r.hip: resident-weight kernel for the 3x3 convs of a 64-channel map (the Upsample convs)
+bool hat_conv64r_can_launch(const HatConvDesc& d);
+int hat_conv64r_launch(const HatConvDesc& d, hipStream_t s);
+
 namespace {
 
 struct TileCfg { int waves, pt; };
@@ -539,8 +543,9 @@ extern "C" int hat_conv(const HatConvDesc* dp, void* stream) {
     int rc = conv_validate(d);
     if (rc) return rc;
     TileCfg tc; size_t lds;
-    if (!conv_pick(d, &tc, &lds)) return HAT_ELDS;
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    if (hat_conv64r_can_launch(d)) return hat_conv64r_launch(d, s);
+    if (!conv_pick(d, &tc, &lds)) return HAT_ELDS;
     if (d.dtype == HAT_BF16) return dispatch_tile<bf16_t>(d, tc, lds, s);
     return dispatch_tile<float>(d, tc, lds, s);
 }
