@@ -217,6 +217,31 @@ int hat_dwconv_gate(const void* u, const float* wdw, const float* bdw, void* out
                     int32_t W, int32_t hid, int32_t ldu, int32_t ldo, int32_t dtype, void* stream);
 
 /*
+ * The OCAB's MLP with its residual in one launch (hat_arch.py:309-313, :391): out = r1 + fc2(GELU(fc1(x))), exact-erf GELU
+ * (the bf16 path's approximation of hat_linear), for embed_dim 144, hidden 288, bf16 (HAT_EUNSUPPORTED otherwise: run the two
+ * hat_linear launches).  The hidden tensor stays in registers.
+ *   x    (B,H,W,ldx) T: LayerNorm2 output;  r1 (B,H,W,ldr1) fp32: the residual stream;
+ *   out  (B,H,W,ldo): fp32 when out_f32 (may alias r1), else T rows (16-byte aligned, ldo % 8 == 0);
+ *   w1f  fc1 as MFMA A fragments [18 n-tiles][4 k-steps][64 lanes][8] bf16 (rows = hidden unit 16 nt + (lane & 15), k = 32 ks +
+ *        8 (lane >> 4) + j), followed by the 16-deep tail [18][64 lanes][4] (k = 128 + 4 (lane >> 4) + j);  b1 [288] fp32;
+ *   w2f  fc2 as A fragments [9 n-tiles][9 k-steps][64 lanes][8] bf16, rows = output channel, k-slot (g = lane >> 4, j) of k-step kk =
+ *        hidden unit 32 kk + 4 g + j (j < 4) or 32 kk + 16 + 4 g + j - 4 (j >= 4);  b2 [144] fp32.
+ */
+typedef struct HatMlpDesc {
+    const void* x;
+    const void* w1f;
+    const float* b1;
+    const void* w2f;
+    const float* b2;
+    const float* r1;
+    void* out;
+    int32_t B, H, W, C, hidden;
+    int32_t ldx, ldr1, ldo;
+    int32_t out_f32, dtype;
+} HatMlpDesc;
+int hat_ocab_mlp(const HatMlpDesc* d, void* stream);
+
+/*
  * HATX's OCAB options (hatx_arch.py:421-449), for the key windows the generic attention kernel is built for (wse = 24, 12 and
  * the odd 25, 13):
  *   hat_ocab_keybias      kb[b][window][key] (fp32, rows of round_up(wse*wse, 16) floats per window: whole key tiles) = tanh(sal at the key's pixel) for a kept key — 0

@@ -45,6 +45,17 @@ class HatConvDesc(C.Structure):
     ]
 
 
+class HatMlpDesc(C.Structure):
+    """Mirror of `struct HatMlpDesc` (include/hat_mi355x.h)."""
+    _fields_ = [
+        ("x", C.c_void_p), ("w1f", C.c_void_p), ("b1", C.c_void_p), ("w2f", C.c_void_p), ("b2", C.c_void_p),
+        ("r1", C.c_void_p), ("out", C.c_void_p),
+        ("B", C.c_int32), ("H", C.c_int32), ("W", C.c_int32), ("C", C.c_int32), ("hidden", C.c_int32),
+        ("ldx", C.c_int32), ("ldr1", C.c_int32), ("ldo", C.c_int32),
+        ("out_f32", C.c_int32), ("dtype", C.c_int32),
+    ]
+
+
 class HatFfnDesc(C.Structure):
     """Mirror of `struct HatFfnDesc` (include/hat_mi355x.h)."""
     _fields_ = [
@@ -85,6 +96,7 @@ SIGNATURES = {
     "hat_abi_version": (C.c_int, []),
     "hat_target_arch": (C.c_char_p, []),
     "hat_conv_tiles": (C.c_int, [C.POINTER(HatConvDesc), C.POINTER(C.c_int32)]),
+    "hat_ocab_mlp": (C.c_int, [C.POINTER(HatMlpDesc), C.c_void_p]),
     "hat_conv_occupancy": (C.c_int, [C.POINTER(HatConvDesc), C.POINTER(C.c_int32)]),
     "hat_conv_plan": (C.c_int, [C.POINTER(HatConvDesc), C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.POINTER(C.c_int32),
                                 C.POINTER(C.c_int64)]),

@@ -191,6 +191,10 @@ class HATEngine:
                 "proj": self._lin(sd, p + ".proj.weight", p + ".proj.bias"),
                 "mlp0": self._lin(sd, p + ".mlp.0.weight", p + ".mlp.0.bias"),
                 "mlp2": self._lin(sd, p + ".mlp.2.weight", p + ".mlp.2.bias"),
+                # both MLP layers in one launch where hat_ocab_mlp is built (HAT_NO_OCAB_MLP=1: the two hat_linear launches)
+                "mlpf": (ops.pack_ocab_mlp(sd[p + ".mlp.0.weight"], sd[p + ".mlp.0.bias"], sd[p + ".mlp.2.weight"], sd[p + ".mlp.2.bias"], dev)
+                         if ops.ocab_mlp_supported(C, sd[p + ".mlp.0.weight"].shape[0], dt) and _r8(C) == C
+                         and not os.environ.get("HAT_NO_OCAB_MLP") else None),
                 "bias_rot": table[rot].t().contiguous().to(dev),  # [heads][M*M]
             }
             if cfg.get("ocab_esc_enable", False):
@@ -402,6 +406,11 @@ class HATEngine:
             else:
                 self._run_lin(oc["proj"], w["ao"], tout, **geo, ldx=ldc, ldo=C, out_mode=O_NHWC_F32, r1=t, ldr1=C)
                 ln(tout, w["n"], oc["n2"])
+            if oc["mlpf"] is not None:   # fc1 + GELU + fc2 + residual fused: the hidden tensor never reaches HBM
+                dst = w["ao"] if as_conv_input else tout
+                ops.ocab_mlp(oc["mlpf"], w["n"], tout, dst, B=B, H=H, W=W, ldx=ldc, ldr1=C, ldo=(ldc if as_conv_input else C),
+                             out_f32=not as_conv_input, dtype=dt)
+                return dst
             self._run_lin(oc["mlp0"], w["n"], w["g"], **geo, ldx=ldc, ldo=w["g"].shape[2], act=ACT_GELU)
             if as_conv_input:
                 self._run_lin(oc["mlp2"], w["g"], w["ao"], **geo, ldx=w["g"].shape[2], ldo=ldc, out_mode=O_NHWC_T, r1=tout, ldr1=C)

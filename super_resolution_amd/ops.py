@@ -11,7 +11,7 @@ import torch
 
 from . import _lib
 from ._lib import (ACT_GELU, ACT_LRELU, ACT_NONE, HAT_BF16, HAT_F32, O_NCHW_F32, O_NHWC_F32, O_NHWC_T, O_PIXSHUF_T,
-                   X_NCHW_F32_MEAN, X_NHWC_F32, X_NHWC_T, HatAggrCabDesc, HatCabFoldDesc, HatConvDesc, HatFfnDesc, HatHabTailDesc)
+                   X_NCHW_F32_MEAN, X_NHWC_F32, X_NHWC_T, HatAggrCabDesc, HatCabFoldDesc, HatConvDesc, HatFfnDesc, HatHabTailDesc, HatMlpDesc)
 
 TORCH_DTYPE = {HAT_F32: torch.float32, HAT_BF16: torch.bfloat16}
 DTYPE_CODE = {"f32": HAT_F32, "fp32": HAT_F32, "float32": HAT_F32, "bf16": HAT_BF16, "bfloat16": HAT_BF16}
@@ -246,6 +246,54 @@ def ocab_attention_kb(q, kv, bias_rot, kb, out, *, B: int, H: int, W: int, C_: i
     _timed(f"ocab_attn_kernel<{_TNAME[dtype]}, kb>", 2.0 * 2 * wse * wse * C_ * B * H * W, lambda: _lib.check(
         lib.hat_ocab_attention_kb(_ptr(q), _ptr(kv), _ptr(bias_rot), _ptr(kb), _ptr(out), B, H, W, C_, heads, ws, wse, pad, ldq, ldkv, ldo,
                                   dtype, _stream()), "hat_ocab_attention_kb"))
+
+
+class PackedMlp:
+    """fc1 / fc2 of the OCAB's MLP in hat_ocab_mlp's fragment layouts (include/hat_mi355x.h)."""
+    __slots__ = ("w1f", "b1", "w2f", "b2", "C", "hidden")
+
+
+def ocab_mlp_supported(C_: int, hidden: int, dtype: int) -> bool:
+    return C_ == 144 and hidden == 288 and dtype == HAT_BF16
+
+
+def pack_ocab_mlp(fc1_w, fc1_b, fc2_w, fc2_b, device) -> PackedMlp:
+    f = lambda t: t.detach().to(torch.float32).cpu()
+    W1, b1, W2, b2 = f(fc1_w), f(fc1_b), f(fc2_w), f(fc2_b)
+    hid, C_ = W1.shape
+    assert (C_, hid) == (144, 288) and W2.shape == (C_, hid)
+    lane = torch.arange(64)
+    n16, g4 = lane & 15, lane >> 4
+    # fc1: full fragments [nt][ks][lane][j] = W1[16 nt + n16][32 ks + 8 g + j], then the 16-deep tail [nt][lane][j] = W1[..][128 + 4 g + j]
+    r = (torch.arange(18)[:, None, None, None] * 16 + n16[None, None, :, None]).expand(18, 4, 64, 8)
+    c = (torch.arange(4)[None, :, None, None] * 32 + 8 * g4[None, None, :, None] + torch.arange(8)[None, None, None, :]).expand(18, 4, 64, 8)
+    full = W1[r, c]
+    rh = (torch.arange(18)[:, None, None] * 16 + n16[None, :, None]).expand(18, 64, 4)
+    ch = (128 + 4 * g4[None, :, None] + torch.arange(4)[None, None, :]).expand(18, 64, 4)
+    half = W1[rh, ch]
+    w1f = torch.cat([full.reshape(-1), half.reshape(-1)])
+    # fc2: [nt2][kk][lane][j] = W2[16 nt2 + n16][unit], unit = 32 kk + 4 g + j (j < 4) | 32 kk + 16 + 4 g + j - 4
+    j8 = torch.arange(8)
+    unit = (torch.arange(9)[:, None, None] * 32 + torch.where(j8[None, None, :] < 4, 4 * g4[None, :, None] + j8[None, None, :],
+                                                               16 + 4 * g4[None, :, None] + j8[None, None, :] - 4))   # (kk, lane, j)
+    r2 = (torch.arange(9)[:, None, None, None] * 16 + n16[None, None, :, None]).expand(9, 9, 64, 8)
+    w2f = W2[r2, unit[None].expand(9, 9, 64, 8)]
+    p = PackedMlp()
+    p.w1f = w1f.to(torch.bfloat16).contiguous().to(device)
+    p.w2f = w2f.to(torch.bfloat16).contiguous().to(device)
+    p.b1, p.b2, p.C, p.hidden = b1.contiguous().to(device), b2.contiguous().to(device), C_, hid
+    return p
+
+
+def ocab_mlp(pm: PackedMlp, x, r1, out, *, B: int, H: int, W: int, ldx: int, ldr1: int, ldo: int, out_f32: bool, dtype: int):
+    """out = r1 + fc2(GELU(fc1(x))) in one launch (hat_ocab_mlp): the 288-wide hidden tensor never reaches HBM."""
+    lib = _lib.load()
+    d = HatMlpDesc()
+    d.x, d.w1f, d.b1, d.w2f, d.b2, d.r1, d.out = _ptr(x), _ptr(pm.w1f), _ptr(pm.b1), _ptr(pm.w2f), _ptr(pm.b2), _ptr(r1), _ptr(out)
+    d.B, d.H, d.W, d.C, d.hidden, d.ldx, d.ldr1, d.ldo, d.out_f32, d.dtype = B, H, W, pm.C, pm.hidden, ldx, ldr1, ldo, int(out_f32), dtype
+    _timed(f"ocab_mlp_kernel<{'true' if out_f32 else 'false'}>", 2.0 * 2 * pm.C * pm.hidden * B * H * W,
+           lambda: _lib.check(lib.hat_ocab_mlp(C.byref(d), _stream()), "hat_ocab_mlp"),
+           tag=f"mlp {pm.C}->{pm.hidden}->{pm.C} {H}x{W}", nbytes=float(B * H * W) * (2 * ldx + 4 * pm.C + (4 if out_f32 else 2) * pm.C))
 
 
 def sgfn_gate(u, wdw, bdw, out, *, B: int, H: int, W: int, half: int, ldu: int, ldo: int, dtype: int):

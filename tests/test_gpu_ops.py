@@ -272,6 +272,32 @@ def test_layernorm(dtype, C):
     check(gap.sum(1)[:, :gap_c] / N, ref[:, :, :gap_c].mean(1), "f32", "gap partial sums", f32_tol=1e-5)
 
 
+@pytest.mark.parametrize("geom", [(2, 24, 40, True), (1, 19, 27, False), (1, 3, 5, True)], ids=["B2_24x40_f32out", "ragged_19x27_bf16out", "15px"])
+def test_ocab_mlp_fused(geom):
+    """hat_ocab_mlp (hat_arch.py:309-313 + the residual of :391): out = r1 + fc2(GELU(fc1(x))) for C = 144, hidden 288, bf16
+    storage, against fp64 torch; fp32 output in place over r1, and T rows (the group conv's input)."""
+    B, H, W, f32out = geom
+    dev, ops = _dev(), _ops()
+    C, hid = 144, 288
+    x = q(rnd("mx", (B, H, W, C)), "bf16")
+    w1, b1 = q(rnd("mw1", (hid, C), std=C ** -0.5), "bf16"), rnd("mb1", (hid,), std=0.2)
+    w2, b2 = q(rnd("mw2", (C, hid), std=hid ** -0.5), "bf16"), rnd("mb2", (C,), std=0.2)
+    r1 = rnd("mr1", (B, H, W, C))
+    hdn = F.gelu(x.double() @ w1.double().t() + b1.double())
+    ref = r1.double() + hdn @ w2.double().t() + b2.double()
+    pm = ops.pack_ocab_mlp(w1, b1, w2, b2, dev)
+    xd = to_dev(x, C, torch.bfloat16, dev)
+    rd = r1.reshape(B, H * W, C).to(dev).contiguous()
+    if f32out:
+        ops.ocab_mlp(pm, xd, rd, rd, B=B, H=H, W=W, ldx=C, ldr1=C, ldo=C, out_f32=True, dtype=ops.HAT_BF16)
+        got = rd
+    else:
+        got = torch.full((B, H * W, C), float("nan"), dtype=torch.bfloat16, device=dev)
+        ops.ocab_mlp(pm, xd, rd, got, B=B, H=H, W=W, ldx=C, ldr1=C, ldo=C, out_f32=False, dtype=ops.HAT_BF16)
+    torch.cuda.synchronize()
+    check(got.float().reshape(B, H, W, C), ref, "bf16", "fused OCAB MLP")
+
+
 @pytest.mark.parametrize("dtype", DT)
 def test_dwconv_gate(dtype):
     dev, ops = _dev(), _ops()
