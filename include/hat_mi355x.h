@@ -240,6 +240,14 @@ typedef struct HatMlpDesc {
     int32_t out_f32, dtype;
 } HatMlpDesc;
 int hat_ocab_mlp(const HatMlpDesc* d, void* stream);
+/*
+ * The OCAB's q and kv projections (hat_arch.py:347, :350) in one launch for embed_dim 144, bf16: out rows of 432 channels
+ * [q | k | v] (T, 16-byte aligned, ldo % 8 == 0) = W x + b.  Uses HatMlpDesc: x, ldx as above; w1f = the stacked weight
+ * [q_proj * head_dim^-0.5 ; kv_proj] (432 x 144) in hat_ocab_mlp's fc1 fragment layout ([27][4][64][8] + [27][64][4]); b1 [432]
+ * (q part scaled likewise); hidden = 432; w2f, b2, r1, ldr1, out_f32 unused.  hat_ocab_attention then takes q = out,
+ * kv = out + 144 elements, ldq = ldkv = ldo.
+ */
+int hat_ocab_qkv(const HatMlpDesc* d, void* stream);
 
 /*
  * HATX's OCAB options (hatx_arch.py:421-449), for the key windows the generic attention kernel is built for (wse = 24, 12 and

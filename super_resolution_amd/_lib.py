@@ -97,6 +97,7 @@ SIGNATURES = {
     "hat_target_arch": (C.c_char_p, []),
     "hat_conv_tiles": (C.c_int, [C.POINTER(HatConvDesc), C.POINTER(C.c_int32)]),
     "hat_ocab_mlp": (C.c_int, [C.POINTER(HatMlpDesc), C.c_void_p]),
+    "hat_ocab_qkv": (C.c_int, [C.POINTER(HatMlpDesc), C.c_void_p]),
     "hat_conv_occupancy": (C.c_int, [C.POINTER(HatConvDesc), C.POINTER(C.c_int32)]),
     "hat_conv_plan": (C.c_int, [C.POINTER(HatConvDesc), C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.POINTER(C.c_int32),
                                 C.POINTER(C.c_int64)]),

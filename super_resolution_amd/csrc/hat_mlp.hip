@@ -144,7 +144,100 @@ __global__ __launch_bounds__(ML_NTHR) void ocab_mlp_kernel(const HatMlpDesc d, l
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------------
+// hat_ocab_qkv: the OCAB's q and kv projections (hat_arch.py:347, :350) as ONE weight-stationary launch for embed_dim 144,
+// bf16: out[p] = [q | k | v] (432 channels, q pre-scaled) = W . x[p] + b.  Two hat_linear launches read the LayerNorm
+// output twice (and share the machine on two streams); here 27 channel tiles x (4 k-steps + the 16-deep tail) = 121.5 KB of A
+// fragments stay in LDS and every 16-pixel tile is read once.
+// ---------------------------------------------------------------------------------------------------------------------------
+constexpr int QK_NT = 27, QK_N = QK_NT * 16;
+constexpr int QK_WF = QK_NT * 4 * 1024, QK_WH = QK_NT * 512, QK_OFF_B = QK_WF + QK_WH, QK_LDS = QK_OFF_B + QK_N * 4;   // 126144 B
+
+__global__ __launch_bounds__(ML_NTHR) void ocab_qkv_kernel(const HatMlpDesc d, long npix, long tiles) {
+    using M = MT<bf16_t>;
+    typedef bf16_t T;
+    typedef M::frag_t frag_t;
+    typedef short s16x4 __attribute__((ext_vector_type(4)));
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63, g = lane >> 4, c16 = lane & 15;
+    const int wave = tid >> 6;
+    {
+        const char* w1 = reinterpret_cast<const char*>(d.w1f);
+        for (int i = tid; i < (QK_WF + QK_WH) / 16; i += ML_NTHR)
+            *reinterpret_cast<u32x4*>(smem + (size_t)i * 16) = *reinterpret_cast<const u32x4*>(w1 + (size_t)i * 16);
+        float* bl = reinterpret_cast<float*>(smem + QK_OFF_B);
+        for (int i = tid; i < QK_N; i += ML_NTHR) bl[i] = d.b1[i];
+    }
+    __syncthreads();
+    const T* xg = reinterpret_cast<const T*>(d.x);
+    const float* bl = reinterpret_cast<const float*>(smem + QK_OFF_B);
+    struct XB { frag_t f[4]; s16x4 h; };
+    auto load_x = [&](long tile, XB& xb) {
+        long p = tile * 16 + c16;
+        p = p < npix ? p : npix - 1;
+        const T* row = xg + p * d.ldx;
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) xb.f[ks] = M::load(row + ks * 32 + 8 * g);
+        xb.h = *reinterpret_cast<const s16x4*>(row + 128 + 4 * g);
+    };
+    const long stride = (long)gridDim.x * ML_WAVES;
+    long tile = (long)blockIdx.x * ML_WAVES + wave;
+    XB xcur, xnxt;
+    load_x(tile, xcur);
+    load_x(tile + stride, xnxt);
+    for (; tile < tiles; tile += stride) {
+        const long p = tile * 16 + c16;
+        const long pc = p < npix ? p : npix - 1;
+        int wofs = lane * 16;
+        asm volatile("" : "+v"(wofs));   // (keeps the loop-invariant fragment reads inside the loop)
+        const char* wl = smem + wofs;
+        const char* wl8 = smem + QK_WF + (wofs >> 1);
+        bf16_t* o = reinterpret_cast<bf16_t*>(d.out) + pc * d.ldo;
+        // channel tiles in pairs: results leave as 16-byte stores while the next pair's MFMAs run
+        f32x4 last = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int np = 0; np < (QK_NT + 1) / 2; ++np) {
+            f32x4 a[2];
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                const int nt = 2 * np + i;
+                if (nt < QK_NT) {
+                    // (the 16-deep tail accumulates separately: see ocab_mlp_kernel)
+                    const s16x4 wh = *reinterpret_cast<const s16x4*>(wl8 + nt * 512);
+                    const f32x4 tail = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(wh, xcur.h, *reinterpret_cast<const f32x4*>(bl + nt * 16 + 4 * g), 0, 0, 0);
+                    a[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                    for (int ks = 0; ks < 4; ++ks)
+                        a[i] = M::mma(*reinterpret_cast<const frag_t*>(wl + (nt * 4 + ks) * 1024), xcur.f[ks], a[i]);
+                    a[i] += tail;
+                }
+            }
+            if (2 * np + 1 < QK_NT) store_pair_bf16(o, 2 * np * 16, g, a[0], a[1]);
+            else last = a[0];
+        }
+        Vec4<T>::store(o + (QK_NT - 1) * 16 + 4 * g, last);
+        xcur = xnxt;
+        load_x(tile + 2 * stride, xnxt);
+    }
+}
+
 }  // namespace
+
+extern "C" int hat_ocab_qkv(const HatMlpDesc* dp, void* stream) {
+    if (!dp) return HAT_EINVAL;
+    const HatMlpDesc& d = *dp;
+    if (!d.x || !d.w1f || !d.b1 || !d.out || d.B < 1 || d.H < 1 || d.W < 1) return HAT_EINVAL;
+    if (d.C != ML_C || d.hidden != QK_N || d.dtype != HAT_BF16) return HAT_EUNSUPPORTED;
+    if (d.ldx < ML_C || d.ldx % 8 || d.ldo < QK_N || d.ldo % 8 || reinterpret_cast<uintptr_t>(d.out) % 16) return HAT_EINVAL;
+    const long npix = (long)d.B * d.H * d.W, tiles = (npix + 15) / 16;
+    int gx = 256;
+    if ((long)gx * ML_WAVES > tiles) gx = (int)((tiles + ML_WAVES - 1) / ML_WAVES);
+    auto kern = ocab_qkv_kernel;
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, QK_LDS);
+    if (e != hipSuccess) return (int)e;
+    HAT_LAUNCH(kern, dim3(gx), dim3(ML_NTHR), QK_LDS, reinterpret_cast<hipStream_t>(stream), d, npix, tiles);
+    return hat_check_launch();
+}
 
 extern "C" int hat_ocab_mlp(const HatMlpDesc* dp, void* stream) {
     if (!dp) return HAT_EINVAL;

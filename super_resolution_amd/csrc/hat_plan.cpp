@@ -55,7 +55,7 @@ struct Reader {
 // function ids: the order of this table is the file format (super_resolution_amd/plan.py FN_IDS mirrors it)
 const char* const FN_NAMES[] = {"hat_conv", "hat_linear", "hat_conv3x3_small", "hat_cab_fold", "hat_aggr_cab", "hat_ffn", "hat_ffn2",
                                 "hat_hab_tail", "hat_layernorm", "hat_esc_weights", "hat_eca_scale", "hat_dwconv_gate", "hat_sgfn_gate",
-                                "hat_ocab_attention", "hat_window_attention", "hat_cab_squeeze", "hat_conv3x3_to_planes", "hat_add_f32", "hat_esc_conv13", "hat_ocab_keybias", "hat_ocab_attention_kb", "hat_ocab_mlp"};
+                                "hat_ocab_attention", "hat_window_attention", "hat_cab_squeeze", "hat_conv3x3_to_planes", "hat_add_f32", "hat_esc_conv13", "hat_ocab_keybias", "hat_ocab_attention_kb", "hat_ocab_mlp", "hat_ocab_qkv"};
 constexpr uint32_t N_FN = sizeof(FN_NAMES) / sizeof(FN_NAMES[0]);
 
 struct Resolved {   // argument values of one call with the pointers patched
@@ -148,6 +148,7 @@ int dispatch(Resolved& r) {
                                                    r.I(10), r.I(11), r.I(12), r.I(13), r.I(14), r.I(15), r.I(16), r.P(17))
                            : HAT_EINVAL;
         case 21: return n == 2 ? hat_ocab_mlp((const HatMlpDesc*)r.P(0), r.P(1)) : HAT_EINVAL;
+        case 22: return n == 2 ? hat_ocab_qkv((const HatMlpDesc*)r.P(0), r.P(1)) : HAT_EINVAL;
         default: return HAT_EUNSUPPORTED;
     }
 }

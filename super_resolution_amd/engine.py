@@ -197,6 +197,12 @@ class HATEngine:
                          and not os.environ.get("HAT_NO_OCAB_MLP") else None),
                 "bias_rot": table[rot].t().contiguous().to(dev),  # [heads][M*M]
             }
+            # q and kv projections in one launch (both read LayerNorm1's output) where hat_ocab_qkv is built and the OCAB has
+            # no ESC on its key / value path (HAT_NO_OCAB_QKV=1: two hat_linear launches on two streams)
+            oc["qkvf"] = (ops.pack_ocab_qkv(sd[p + ".q_proj.weight"], sd.get(p + ".q_proj.bias"), sd[p + ".kv_proj.weight"],
+                                            sd.get(p + ".kv_proj.bias"), qscale, dev)
+                          if C == 144 and dt == ops.HAT_BF16 and not cfg.get("ocab_esc_enable", False)
+                          and not os.environ.get("HAT_NO_OCAB_QKV") else None)
             if cfg.get("ocab_esc_enable", False):
                 oc["esc"] = _ESC(sd, p + ".esc_core", p + ".esc_plk", cfg["ocab_esc_pdim"], cfg["ocab_esc_kernel"], C, dt, dev)
                 oc["esc"].aggr = self._lin(sd, *oc["esc"].aggr_keys)
@@ -262,6 +268,8 @@ class HATEngine:
             "gap": z(B, max(ops.layernorm_blocks(), -(-H // 4) * -(-W // 16)), yw, dtype=f),
             "scale": z(B, 256, dtype=f), "eca_tmp": z(B, 32, 256, dtype=f),
         }
+        if any(L["ocab"].get("qkvf") is not None for L in self.layers):
+            w["qkv"] = z(B, N, 432)      # [q | k | v] rows of the fused projection
         esc0 = self.layers[0]["habs"][0]["esc"] if self.layers and self.layers[0]["habs"] else None
         kpad = max([esc0.kpad if esc0 else 0] + [L["ocab"]["esc"].kpad for L in self.layers if "esc" in L["ocab"]])
         w["weff"] = z(B, yw, max(kpad, 64))
@@ -380,25 +388,30 @@ class HATEngine:
                 self._esc_lk(esc, w, w["n"], B, H, W, nblk)
                 self._run_lin(esc.aggr, w["n"], w["yesc"], **geo, ldx=ldc, ldo=ldc, x0=w["y16"], c_split=esc.pdim, ldx0=w["y16"].shape[2])
                 kv_src = w["yesc"]
-            s0, s1 = torch.cuda.current_stream(self.dev), self._side_stream()   # q and kv projections are independent
-            s1.wait_stream(s0)
-            with torch.cuda.stream(s1):
-                self._run_lin(oc["q"], w["n"], w["q"], **geo, ldx=ldc, ldo=ldc)
-            self._run_lin(oc["kv"], kv_src, w["kv"], **geo, ldx=ldc, ldo=w["kv"].shape[2])
-            s0.wait_stream(s1)
+            qbuf, kvbuf, ldq, ldkv = w["q"], w["kv"], ldc, w["kv"].shape[2]
+            if oc.get("qkvf") is not None and esc is None:
+                ops.ocab_qkv(oc["qkvf"], w["n"], w["qkv"], B=B, H=H, W=W, ldx=ldc, ldo=432, dtype=dt)
+                qbuf, kvbuf, ldq, ldkv = w["qkv"], w["qkv"].view(-1)[144:], 432, 432
+            else:
+                s0, s1 = torch.cuda.current_stream(self.dev), self._side_stream()   # q and kv projections are independent
+                s1.wait_stream(s0)
+                with torch.cuda.stream(s1):
+                    self._run_lin(oc["q"], w["n"], w["q"], **geo, ldx=ldc, ldo=ldc)
+                self._run_lin(oc["kv"], kv_src, w["kv"], **geo, ldx=ldc, ldo=w["kv"].shape[2])
+                s0.wait_stream(s1)
             if self.focus or self.topk < 1.0:   # HATX: focus bias on the logits and / or top-k key pruning   hatx_arch.py:421-449
                 nk, pad = self.wse * self.wse, (self.wse - ws + 1) // 2
                 if self.focus:
                     ops.conv(oc["fh0"], kv_src, w["fh"], **geo, ldx=ldc, ldo=w["fh"].shape[2], act=ACT_GELU, n_store=_r4(C // 4))
                     ops.conv(oc["fh2"], w["fh"], w["sal"], **geo, ldx=w["fh"].shape[2], ldo=8, n_store=4)
                 k_keep = max(1, int(self.topk * nk)) if self.topk < 1.0 else nk
-                ops.ocab_keybias(w["sal"] if self.focus else None, w["kv"], w["kb"], B=B, H=H, W=W, C_=C, ws=ws, wse=self.wse, pad=pad,
-                                 k_keep=k_keep, ldsal=8, ldkv=w["kv"].shape[2], dtype=dt)
-                ops.ocab_attention_kb(w["q"], w["kv"], oc["bias_rot"], w["kb"], w["ao"], B=B, H=H, W=W, C_=C, heads=L["heads"], ws=ws,
-                                      wse=self.wse, pad=pad, ldq=ldc, ldkv=w["kv"].shape[2], ldo=ldc, dtype=dt)
+                ops.ocab_keybias(w["sal"] if self.focus else None, kvbuf, w["kb"], B=B, H=H, W=W, C_=C, ws=ws, wse=self.wse, pad=pad,
+                                 k_keep=k_keep, ldsal=8, ldkv=ldkv, dtype=dt)
+                ops.ocab_attention_kb(qbuf, kvbuf, oc["bias_rot"], w["kb"], w["ao"], B=B, H=H, W=W, C_=C, heads=L["heads"], ws=ws,
+                                      wse=self.wse, pad=pad, ldq=ldq, ldkv=ldkv, ldo=ldc, dtype=dt)
             else:
-                ops.ocab_attention(w["q"], w["kv"], oc["bias_rot"], w["ao"], B=B, H=H, W=W, C_=C, heads=L["heads"], ws=ws,
-                                   wse=self.wse, ldq=ldc, ldkv=w["kv"].shape[2], ldo=ldc, dtype=dt)
+                ops.ocab_attention(qbuf, kvbuf, oc["bias_rot"], w["ao"], B=B, H=H, W=W, C_=C, heads=L["heads"], ws=ws,
+                                   wse=self.wse, ldq=ldq, ldkv=ldkv, ldo=ldc, dtype=dt)
             tout = tB if t is tA else t  # never write the RHAG input buffer
             if oc["proj"].frag:  # norm2 (:306) rides on the projection's epilogue
                 self._run_lin(oc["proj"], w["ao"], tout, **geo, ldx=ldc, ldo=C, out_mode=O_NHWC_F32, r1=t, ldr1=C,

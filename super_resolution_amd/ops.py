@@ -285,6 +285,44 @@ def pack_ocab_mlp(fc1_w, fc1_b, fc2_w, fc2_b, device) -> PackedMlp:
     return p
 
 
+def _pack_fc1_frags(W1: torch.Tensor) -> torch.Tensor:
+    """(16 nt, 144) fp32 -> hat_ocab_mlp's fc1 layout: [nt][4][64 lanes][8] full k-steps then [nt][64][4] the 16-deep tail."""
+    nt_ = W1.shape[0] // 16
+    lane = torch.arange(64)
+    n16, g4 = lane & 15, lane >> 4
+    r = (torch.arange(nt_)[:, None, None, None] * 16 + n16[None, None, :, None]).expand(nt_, 4, 64, 8)
+    c = (torch.arange(4)[None, :, None, None] * 32 + 8 * g4[None, None, :, None] + torch.arange(8)[None, None, None, :]).expand(nt_, 4, 64, 8)
+    rh = (torch.arange(nt_)[:, None, None] * 16 + n16[None, :, None]).expand(nt_, 64, 4)
+    ch = (128 + 4 * g4[None, :, None] + torch.arange(4)[None, None, :]).expand(nt_, 64, 4)
+    return torch.cat([W1[r, c].reshape(-1), W1[rh, ch].reshape(-1)])
+
+
+def pack_ocab_qkv(q_w, q_b, kv_w, kv_b, qscale: float, device) -> PackedMlp:
+    """Stacked [q_proj * qscale ; kv_proj] (432 x 144) for hat_ocab_qkv."""
+    f = lambda t: t.detach().to(torch.float32).cpu()
+    Wq, Wkv = f(q_w) * qscale, f(kv_w)
+    bq = (torch.zeros(Wq.shape[0]) if q_b is None else f(q_b)) * qscale
+    bkv = torch.zeros(Wkv.shape[0]) if kv_b is None else f(kv_b)
+    W = torch.cat([Wq, Wkv], 0)
+    assert W.shape == (432, 144)
+    p = PackedMlp()
+    p.w1f = _pack_fc1_frags(W).to(torch.bfloat16).contiguous().to(device)
+    p.b1 = torch.cat([bq, bkv]).contiguous().to(device)
+    p.w2f = p.b2 = None
+    p.C, p.hidden = 144, 432
+    return p
+
+
+def ocab_qkv(pm: PackedMlp, x, out, *, B: int, H: int, W: int, ldx: int, ldo: int, dtype: int):
+    """out rows [q | k | v] (432 channels) = both OCAB projections of x in one launch (hat_ocab_qkv)."""
+    lib = _lib.load()
+    d = HatMlpDesc()
+    d.x, d.w1f, d.b1, d.out = _ptr(x), _ptr(pm.w1f), _ptr(pm.b1), _ptr(out)
+    d.B, d.H, d.W, d.C, d.hidden, d.ldx, d.ldo, d.dtype = B, H, W, pm.C, pm.hidden, ldx, ldo, dtype
+    _timed("ocab_qkv_kernel", 2.0 * pm.C * pm.hidden * B * H * W, lambda: _lib.check(lib.hat_ocab_qkv(C.byref(d), _stream()), "hat_ocab_qkv"),
+           tag=f"qkv {pm.C}->{pm.hidden} {H}x{W}", nbytes=float(B * H * W) * 2 * (ldx + pm.hidden))
+
+
 def ocab_mlp(pm: PackedMlp, x, r1, out, *, B: int, H: int, W: int, ldx: int, ldr1: int, ldo: int, out_f32: bool, dtype: int):
     """out = r1 + fc2(GELU(fc1(x))) in one launch (hat_ocab_mlp): the 288-wide hidden tensor never reaches HBM."""
     lib = _lib.load()

@@ -298,6 +298,22 @@ def test_ocab_mlp_fused(geom):
     check(got.float().reshape(B, H, W, C), ref, "bf16", "fused OCAB MLP")
 
 
+def test_ocab_qkv_fused():
+    """hat_ocab_qkv: [q * d^-0.5 | k | v] = both OCAB projections (hat_arch.py:347, :350, :375) of one 144-channel map, bf16."""
+    dev, ops = _dev(), _ops()
+    B, H, W, C = 2, 19, 27, 144
+    x = q(rnd("qx", (B, H, W, C)), "bf16")
+    wq, bq = rnd("qw", (C, C), std=C ** -0.5), rnd("qb", (C,), std=0.2)
+    wkv, bkv = rnd("kvw", (2 * C, C), std=C ** -0.5), rnd("kvb", (2 * C,), std=0.2)
+    sc = 24 ** -0.5
+    ref = torch.cat([(x.double() @ q(wq * sc, "bf16").double().t() + bq.double() * sc), x.double() @ q(wkv, "bf16").double().t() + bkv.double()], -1)
+    pm = ops.pack_ocab_qkv(wq, bq, wkv, bkv, sc, dev)
+    out = torch.full((B, H * W, 432), float("nan"), dtype=torch.bfloat16, device=dev)
+    ops.ocab_qkv(pm, to_dev(x, C, torch.bfloat16, dev), out, B=B, H=H, W=W, ldx=C, ldo=432, dtype=ops.HAT_BF16)
+    torch.cuda.synchronize()
+    check(out.float().reshape(B, H, W, 432), ref, "bf16", "fused q / kv projection")
+
+
 @pytest.mark.parametrize("dtype", DT)
 def test_dwconv_gate(dtype):
     dev, ops = _dev(), _ops()
