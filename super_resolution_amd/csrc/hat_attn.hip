@@ -9,6 +9,8 @@
 // cross-lane shuffles; P^T feeds the second MFMA (O^T = V^T.P^T) straight from the accumulator
 // registers — the contraction index (key) ordering inside a 32-wide k-step is permuted
 // identically for both operands, so no LDS round trip or lane movement is needed for P.
+#include <cstdlib>
+
 #include "hat_common.h"
 
 namespace {
@@ -229,15 +231,20 @@ __device__ __forceinline__ float max3_raw(float a, float b, float c) {
 // window self-attention for hat_window_attention — the key window is the query window, all coordinates live on the frame
 // shifted cyclically by `shift` (so every key is a real pixel), and in the last window row / column the -100 of the
 // shift mask is added to the scores of pairs in different mask bands.
-template <int D, int WSE, bool SELF>
-__global__ __launch_bounds__(256, WSE == 24 ? 2 : 4) void ocab_attn_fast_kernel(const bf16_t* __restrict__ q, const bf16_t* __restrict__ kv,
+// NTH: threads per workgroup.  512 (the OCAB of the C = 144 models) = eight waves with two query rows each and key chunks of 6
+// tiles (half the score registers: 80 VGPRs): the K / V image of a 24 x 24 key window (64.5 KB) limits a CU to two workgroups,
+// and sixteen waves instead of eight hide more of the softmax's latencies (0.995 -> 0.955 ms at 720p; sixteen-wave workgroups
+// measured the same as eight).
+template <int D, int WSE, bool SELF, int NTH = 256>
+__global__ __launch_bounds__(NTH, WSE == 24 ? 2 : 4) void ocab_attn_fast_kernel(const bf16_t* __restrict__ q, const bf16_t* __restrict__ kv,
                                                                 const float* __restrict__ bias_rot, bf16_t* __restrict__ out,
                                                                 int B, int H, int W, int C, int heads, int ldq, int ldkv,
                                                                 int ldo, int shift) {
     using M = MT<bf16_t>;
     using frag_t = M::frag_t;
-    constexpr int WS = 16, NK = WSE * WSE, MR = WS + WSE - 1, NKT = NK / 16, KCH = WSE == 24 ? 12 : 8, PAD = (WSE - WS) / 2;
-    constexpr int CH_ROWS = KCH * 16 / WSE;  // key rows per chunk (8 for both geometries)
+    constexpr int WS = 16, NK = WSE * WSE, MR = WS + WSE - 1, NKT = NK / 16, KCH = WSE == 24 ? (NTH >= 512 ? 6 : 12) : 8, PAD = (WSE - WS) / 2;
+    constexpr int CH_ROWS = KCH * 16 / WSE;  // key rows per chunk
+    static_assert(KCH % 2 == 0 && KCH * 16 % WSE == 0, "a chunk is whole key rows and whole pairs of key tiles");
     static_assert(!SELF || WSE == WS, "self-attention windows coincide with the query windows");
     constexpr int KR = D == 24 ? 24 : 32;   // K row length in LDS (elements)
     constexpr int ONE = D == 24 ? 24 : 30;  // V column that holds 1.0 (the softmax denominator row of O^T)
@@ -276,28 +283,29 @@ __global__ __launch_bounds__(256, WSE == 24 ? 2 : 4) void ocab_attn_fast_kernel(
         return img + (size_t)min(max(y, 0), H - 1) * W + min(max(x, 0), W - 1);
     };
 
-    frag_t qfr[4];   // this wave's four query tiles: query tile qt = window row qt, lane c16 = window column
-    constexpr int NTAB = (MR * MR + 255) / 256;
+    constexpr int NWV = NTH / 64, QPW = 16 / NWV;   // waves, query rows (tiles) per wave
+    frag_t qfr[QPW];   // this wave's query tiles: query tile qt = window row qt, lane c16 = window column
+    constexpr int NTAB = (MR * MR + NTH - 1) / NTH;
     float tv[NTAB];
 #pragma unroll
     for (int it = 0; it < NTAB; ++it) {
-        const int i = tid + it * 256;
+        const int i = tid + it * NTH;
         tv[it] = bias_rot[(size_t)h * MR * MR + (i < MR * MR ? i : MR * MR - 1)];
     }
     if constexpr (D == 24) {
         // Every global load of the staging phase is issued before the first LDS store (branch-free: out-of-image keys
         // load a clamped pixel and are zeroed by a select), so the phase costs one memory latency, not nine.
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const size_t qpix = qpixel(wave + 4 * i, c16);
+        for (int i = 0; i < QPW; ++i) {
+            const size_t qpix = qpixel(wave + NWV * i, c16);
             qfr[i] = M::load(q + qpix * ldq + h * D + 8 * (g < 3 ? g : 2));
             if (g == 3) qfr[i] = M::zero();
         }
-        constexpr int NIT = NK * 4 / 256;
+        constexpr int NIT = (NK * 4 + NTH - 1) / NTH;   // (the last pass is partial with 512 threads: clamped loads, masked stores)
         u32x4 kq[NIT], vq[NIT];
 #pragma unroll
         for (int it = 0; it < NIT; ++it) {
-            const int i = tid + it * 256;
+            const int i = min(tid + it * NTH, NK * 4 - 1);
             const int key = i >> 2, c = i & 3;
             const int kh = key / WSE, kw = key - kh * WSE;
             bool inb;
@@ -307,7 +315,7 @@ __global__ __launch_bounds__(256, WSE == 24 ? 2 : 4) void ocab_attn_fast_kernel(
         }
 #pragma unroll
         for (int it = 0; it < NIT; ++it) {
-            const int i = tid + it * 256;
+            const int i = tid + it * NTH;
             const int key = i >> 2, c = i & 3;
             const int kh = key / WSE, kw = key - kh * WSE;
             bool inb;
@@ -316,14 +324,16 @@ __global__ __launch_bounds__(256, WSE == 24 ? 2 : 4) void ocab_attn_fast_kernel(
             const u32x4 zero = {0u, 0u, 0u, 0u};
             // channel 24 = 1.0 for EVERY key (out-of-image keys still count in the softmax denominator)
             const u32x4 vval = c == 3 ? u32x4{0x00003F80u, 0u, 0u, 0u} : (inb ? vq[it] : zero);
-            *reinterpret_cast<u32x4*>(Vs + key * 32 + 8 * (c ^ vsw)) = vval;
-            if (c < 3) *reinterpret_cast<u32x4*>(Ks + key * KR + 8 * c) = inb ? kq[it] : zero;
+            if (NIT * NTH == NK * 4 || i < NK * 4) {
+                *reinterpret_cast<u32x4*>(Vs + key * 32 + 8 * (c ^ vsw)) = vval;
+                if (c < 3) *reinterpret_cast<u32x4*>(Ks + key * KR + 8 * c) = inb ? kq[it] : zero;
+            }
         }
     } else {
         // 4-byte staging: dword dw (two channels) of key `key`; dword 15 is the pad of K and [1.0, 0] of V
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const size_t qpix = qpixel(wave + 4 * i, c16);
+        for (int i = 0; i < QPW; ++i) {
+            const size_t qpix = qpixel(wave + NWV * i, c16);
             const unsigned* qp = reinterpret_cast<const unsigned*>(q + qpix * ldq + h * D) + 4 * g;
             u32x4 v;
 #pragma unroll
@@ -331,15 +341,15 @@ __global__ __launch_bounds__(256, WSE == 24 ? 2 : 4) void ocab_attn_fast_kernel(
             if (g == 3) v[3] = 0u;   // channels 30, 31
             qfr[i] = __builtin_bit_cast(frag_t, v);
         }
-        constexpr int BATCH = WSE == 24 ? 12 : 8, NPASS = NK * 16 / 256 / BATCH;
-        static_assert(NPASS * BATCH * 256 == NK * 16, "staging passes must cover the key window exactly");
+        constexpr int BATCH = WSE == 24 ? 12 : 8, NPASS = NK * 16 / NTH / BATCH;
+        static_assert(NPASS * BATCH * NTH == NK * 16, "staging passes must cover the key window exactly");
         unsigned* Kd = reinterpret_cast<unsigned*>(Ks);
         unsigned* Vd = reinterpret_cast<unsigned*>(Vs);
         for (int ps = 0; ps < NPASS; ++ps) {
             unsigned kq[BATCH], vq[BATCH];
 #pragma unroll
             for (int it = 0; it < BATCH; ++it) {
-                const int i = tid + (ps * BATCH + it) * 256;
+                const int i = tid + (ps * BATCH + it) * NTH;
                 const int key = i >> 4, dw = i & 15;
                 const int kh = key / WSE, kw = key - kh * WSE;
                 bool inb;
@@ -349,7 +359,7 @@ __global__ __launch_bounds__(256, WSE == 24 ? 2 : 4) void ocab_attn_fast_kernel(
             }
 #pragma unroll
             for (int it = 0; it < BATCH; ++it) {
-                const int i = tid + (ps * BATCH + it) * 256;
+                const int i = tid + (ps * BATCH + it) * NTH;
                 const int key = i >> 4, dw = i & 15;
                 const int kh = key / WSE, kw = key - kh * WSE;
                 bool inb;
@@ -362,7 +372,7 @@ __global__ __launch_bounds__(256, WSE == 24 ? 2 : 4) void ocab_attn_fast_kernel(
     }
 #pragma unroll
     for (int it = 0; it < NTAB; ++it) {
-        const int i = tid + it * 256;
+        const int i = tid + it * NTH;
         if (i < MR * MR) tab[i] = tv[it];
     }
     __syncthreads();
@@ -379,8 +389,8 @@ __global__ __launch_bounds__(256, WSE == 24 ? 2 : 4) void ocab_attn_fast_kernel(
         toff[t] = (kh + WS - 1) * MR + (kw - c16 + WS - 1);
     }
 #pragma unroll
-    for (int qi4 = 0; qi4 < 4; ++qi4) {
-        const int qt = wave + 4 * qi4;
+    for (int qi4 = 0; qi4 < QPW; ++qi4) {
+        const int qt = wave + NWV * qi4;
         const size_t qpix = qpixel(qt, c16);
         const frag_t qf = qfr[qi4];
         // D = 24: lanes g == 3 meet a zero Q fragment and re-read group 2; D = 30: 4 slots per row, XOR-swizzled by the row
@@ -565,11 +575,13 @@ extern "C" int hat_ocab_attention(const void* q, const void* kv, const float* bi
     const bool fast30 = d == 30 && ldq % 2 == 0 && ldkv % 2 == 0 && ldo % 2 == 0 && C % 2 == 0;
     if (dtype == HAT_BF16 && ws == 16 && wse == 24 && (fast24 || fast30)) {
         const size_t lds = (size_t)576 * (fast24 ? 24 : 32) * 2 + (size_t)576 * 32 * 2 + (size_t)39 * 39 * 4;
-        auto kern = fast24 ? ocab_attn_fast_kernel<24, 24, false> : ocab_attn_fast_kernel<30, 24, false>;
+        static const bool w4 = getenv("HAT_ATTN_4WAVES") != nullptr;   // (A/B switch: round 1's four-wave workgroups)
+        auto kern = fast24 ? (w4 ? ocab_attn_fast_kernel<24, 24, false> : ocab_attn_fast_kernel<24, 24, false, 512>) : ocab_attn_fast_kernel<30, 24, false>;
+        const int nth = fast24 && !w4 ? 512 : 256;
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return (int)e;
         const int nwin = B * (W / ws) * (H / ws);
-        HAT_LAUNCH(kern, dim3((nwin + 7) / 8 * 8 * heads), dim3(256), lds, s, reinterpret_cast<const bf16_t*>(q),
+        HAT_LAUNCH(kern, dim3((nwin + 7) / 8 * 8 * heads), dim3(nth), lds, s, reinterpret_cast<const bf16_t*>(q),
                    reinterpret_cast<const bf16_t*>(kv), bias_rot, reinterpret_cast<bf16_t*>(out), B, H, W, C, heads, ldq, ldkv, ldo, 0);
         return hat_check_launch();
     }
