@@ -341,7 +341,7 @@ __global__ __launch_bounds__(NTH, WSE == 24 ? 2 : 4) void ocab_attn_fast_kernel(
             if (g == 3) v[3] = 0u;   // channels 30, 31
             qfr[i] = __builtin_bit_cast(frag_t, v);
         }
-        constexpr int BATCH = WSE == 24 ? 12 : 8, NPASS = NK * 16 / NTH / BATCH;
+        constexpr int BATCH = WSE == 24 ? (NTH == 512 ? 9 : 12) : 8, NPASS = NK * 16 / NTH / BATCH;
         static_assert(NPASS * BATCH * NTH == NK * 16, "staging passes must cover the key window exactly");
         unsigned* Kd = reinterpret_cast<unsigned*>(Ks);
         unsigned* Vd = reinterpret_cast<unsigned*>(Vs);
@@ -576,8 +576,9 @@ extern "C" int hat_ocab_attention(const void* q, const void* kv, const float* bi
     if (dtype == HAT_BF16 && ws == 16 && wse == 24 && (fast24 || fast30)) {
         const size_t lds = (size_t)576 * (fast24 ? 24 : 32) * 2 + (size_t)576 * 32 * 2 + (size_t)39 * 39 * 4;
         static const bool w4 = getenv("HAT_ATTN_4WAVES") != nullptr;   // (A/B switch: round 1's four-wave workgroups)
-        auto kern = fast24 ? (w4 ? ocab_attn_fast_kernel<24, 24, false> : ocab_attn_fast_kernel<24, 24, false, 512>) : ocab_attn_fast_kernel<30, 24, false>;
-        const int nth = fast24 && !w4 ? 512 : 256;
+        auto kern = fast24 ? (w4 ? ocab_attn_fast_kernel<24, 24, false> : ocab_attn_fast_kernel<24, 24, false, 512>)
+                           : (w4 ? ocab_attn_fast_kernel<30, 24, false> : ocab_attn_fast_kernel<30, 24, false, 512>);
+        const int nth = w4 ? 256 : 512;
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return (int)e;
         const int nwin = B * (W / ws) * (H / ws);

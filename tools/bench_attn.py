@@ -8,18 +8,21 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from super_resolution_amd import ops  # noqa: E402
 
 dev = torch.device("cuda:0")
-C, heads, ws, wse, H, W = 144, 6, 16, 24, 720, 1280
+import sys as _s
+C = int(_s.argv[1]) if len(_s.argv) > 1 else 144
+heads, ws, wse, H, W = 6, 16, 24, 720, 1280
 dt = ops.HAT_BF16
-q = torch.randn(1, H * W, C, device=dev).to(torch.bfloat16)
-kv = torch.randn(1, H * W, 2 * C, device=dev).to(torch.bfloat16)
+LD = (C + 7) // 8 * 8
+q = torch.randn(1, H * W, LD, device=dev).to(torch.bfloat16)
+kv = torch.randn(1, H * W, 2 * LD, device=dev).to(torch.bfloat16)
 M = ws + wse - 1
 bias = torch.randn(heads, M * M, device=dev) * 0.1
-out = torch.empty(1, H * W, C, dtype=torch.bfloat16, device=dev)
+out = torch.empty(1, H * W, LD, dtype=torch.bfloat16, device=dev)
 a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
 for i in range(23):
     if i == 3:
         a.record()
-    ops.ocab_attention(q, kv, bias, out, B=1, H=H, W=W, C_=C, heads=heads, ws=ws, wse=wse, ldq=C, ldkv=2 * C, ldo=C, dtype=dt)
+    ops.ocab_attention(q, kv, bias, out, B=1, H=H, W=W, C_=C, heads=heads, ws=ws, wse=wse, ldq=LD, ldkv=2 * LD, ldo=LD, dtype=dt)
 b.record()
 torch.cuda.synchronize()
-print(f"ocab attention 720p: {a.elapsed_time(b) / 20:.3f} ms per launch")
+print(f"ocab attention 720p C={C}: {a.elapsed_time(b) / 20:.3f} ms per launch")
