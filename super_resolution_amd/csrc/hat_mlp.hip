@@ -12,12 +12,13 @@
 // 4g..4g+3 of a 16-unit tile) IS the B operand of fc2 when fc2's k-slot (g, j) is defined as unit 4g + j of tile 2kk
 // (j < 4) or of tile 2kk + 1 (j >= 4) — ops.pack_ocab_mlp orders fc2's fragments that way (the trick of the attention
 // kernel's P fragment and of hat_ffn2's gate).
+#include <cstdlib>
+
 #include "hat_common.h"
 
 namespace {
 
 constexpr int ML_C = 144, ML_HID = 288, ML_NT1 = ML_HID / 16, ML_NT2 = ML_C / 16, ML_KK = ML_HID / 32;   // 18, 9, 9
-constexpr int ML_WAVES = 8, ML_NTHR = ML_WAVES * 64;
 constexpr int ML_W1F = ML_NT1 * 4 * 1024;          // fc1 full fragments  [nt][ks 0..3][64 lanes][8]      73728
 constexpr int ML_W1H = ML_NT1 * 512;               // fc1 half fragments  [nt][64 lanes][4] (channels 128..143)  9216
 constexpr int ML_NREG = 4;                         // fc2 fragments kept in registers: (nt2 = 8, kk = 5..8)
@@ -25,8 +26,9 @@ constexpr int ML_W2F = (ML_NT2 * ML_KK - ML_NREG) * 1024;   // 78848
 constexpr int ML_OFF_W1H = ML_W1F, ML_OFF_W2 = ML_W1F + ML_W1H, ML_OFF_B1 = ML_OFF_W2 + ML_W2F, ML_OFF_B2 = ML_OFF_B1 + ML_HID * 4;
 constexpr int ML_LDS = ML_OFF_B2 + ML_C * 4;       // 163520 <= 163840
 
-template <bool OUTF32>
-__global__ __launch_bounds__(ML_NTHR) void ocab_mlp_kernel(const HatMlpDesc d, long npix, long tiles) {
+template <bool OUTF32, int WAVES>
+__global__ __launch_bounds__(WAVES * 64) void ocab_mlp_kernel(const HatMlpDesc d, long npix, long tiles) {
+    constexpr int ML_NTHR = WAVES * 64, ML_WAVES = WAVES;
     using M = MT<bf16_t>;
     typedef bf16_t T;
     typedef M::frag_t frag_t;
@@ -153,7 +155,9 @@ __global__ __launch_bounds__(ML_NTHR) void ocab_mlp_kernel(const HatMlpDesc d, l
 constexpr int QK_NT = 27, QK_N = QK_NT * 16;
 constexpr int QK_WF = QK_NT * 4 * 1024, QK_WH = QK_NT * 512, QK_OFF_B = QK_WF + QK_WH, QK_LDS = QK_OFF_B + QK_N * 4;   // 126144 B
 
-__global__ __launch_bounds__(ML_NTHR) void ocab_qkv_kernel(const HatMlpDesc d, long npix, long tiles) {
+template <int WAVES>
+__global__ __launch_bounds__(WAVES * 64) void ocab_qkv_kernel(const HatMlpDesc d, long npix, long tiles) {
+    constexpr int ML_NTHR = WAVES * 64, ML_WAVES = WAVES;
     using M = MT<bf16_t>;
     typedef bf16_t T;
     typedef M::frag_t frag_t;
@@ -230,12 +234,14 @@ extern "C" int hat_ocab_qkv(const HatMlpDesc* dp, void* stream) {
     if (d.C != ML_C || d.hidden != QK_N || d.dtype != HAT_BF16) return HAT_EUNSUPPORTED;
     if (d.ldx < ML_C || d.ldx % 8 || d.ldo < QK_N || d.ldo % 8 || reinterpret_cast<uintptr_t>(d.out) % 16) return HAT_EINVAL;
     const long npix = (long)d.B * d.H * d.W, tiles = (npix + 15) / 16;
+    static const int waves = getenv("HAT_QKV_WAVES") ? atoi(getenv("HAT_QKV_WAVES")) : 8;    // (A/B switch: 8 or 16 waves per workgroup; no difference measured)
+    const int nw = waves == 8 ? 8 : 16;
     int gx = 256;
-    if ((long)gx * ML_WAVES > tiles) gx = (int)((tiles + ML_WAVES - 1) / ML_WAVES);
-    auto kern = ocab_qkv_kernel;
+    if ((long)gx * nw > tiles) gx = (int)((tiles + nw - 1) / nw);
+    auto kern = nw == 8 ? ocab_qkv_kernel<8> : ocab_qkv_kernel<16>;
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, QK_LDS);
     if (e != hipSuccess) return (int)e;
-    HAT_LAUNCH(kern, dim3(gx), dim3(ML_NTHR), QK_LDS, reinterpret_cast<hipStream_t>(stream), d, npix, tiles);
+    HAT_LAUNCH(kern, dim3(gx), dim3(nw * 64), QK_LDS, reinterpret_cast<hipStream_t>(stream), d, npix, tiles);
     return hat_check_launch();
 }
 
@@ -248,19 +254,15 @@ extern "C" int hat_ocab_mlp(const HatMlpDesc* dp, void* stream) {
     if (d.ldx < ML_C || d.ldx % 8 || d.ldr1 < ML_C || d.ldr1 % 4 || d.ldo < ML_C) return HAT_EINVAL;
     if (d.out_f32 ? d.ldo % 4 : (d.ldo % 8 || reinterpret_cast<uintptr_t>(d.out) % 16)) return HAT_EINVAL;
     const long npix = (long)d.B * d.H * d.W, tiles = (npix + 15) / 16;
+    static const int waves = getenv("HAT_MLP_WAVES") ? atoi(getenv("HAT_MLP_WAVES")) : 8;    // (A/B switch; 16 waves spill at 128 registers and measured slower)
+    const int nw = waves == 8 ? 8 : 16;
     int gx = 256;
-    if ((long)gx * ML_WAVES > tiles) gx = (int)((tiles + ML_WAVES - 1) / ML_WAVES);
+    if ((long)gx * nw > tiles) gx = (int)((tiles + nw - 1) / nw);
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
-    if (d.out_f32) {
-        auto kern = ocab_mlp_kernel<true>;
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, ML_LDS);
-        if (e != hipSuccess) return (int)e;
-        HAT_LAUNCH(kern, dim3(gx), dim3(ML_NTHR), ML_LDS, s, d, npix, tiles);
-    } else {
-        auto kern = ocab_mlp_kernel<false>;
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, ML_LDS);
-        if (e != hipSuccess) return (int)e;
-        HAT_LAUNCH(kern, dim3(gx), dim3(ML_NTHR), ML_LDS, s, d, npix, tiles);
-    }
+    void (*kern)(const HatMlpDesc, long, long) = d.out_f32 ? (nw == 8 ? ocab_mlp_kernel<true, 8> : ocab_mlp_kernel<true, 16>)
+                                                            : (nw == 8 ? ocab_mlp_kernel<false, 8> : ocab_mlp_kernel<false, 16>);
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, ML_LDS);
+    if (e != hipSuccess) return (int)e;
+    HAT_LAUNCH(kern, dim3(gx), dim3(nw * 64), ML_LDS, s, d, npix, tiles);
     return hat_check_launch();
 }
