@@ -471,22 +471,31 @@ class HATEngine:
                     # convs they do not depend on: esc_weights beside the CAB squeeze conv, cab_fold beside the 13x13 conv.
                     fo = hb["fold"]
                     s0, s1 = torch.cuda.current_stream(self.dev), self._side_stream()
-                    # The (tiny, latency-bound) ESC weight kernel goes first on the main stream: launched beside the
-                    # squeeze conv it waited for that kernel's waves to retire (they hold every register file for the
-                    # whole launch), and the 13x13 conv behind it started only then.
-                    self._esc_w(esc, w, B, H, W, nblk)
-                    s1.wait_stream(s0)                              # n and the 13x13 weights are ready
-                    with torch.cuda.stream(s1):                     # chain 2: 13x13 conv
-                        self._esc_conv(esc, w, w["n"], B, H, W, n16=(w["n16"] if have_n16 else None))
-                    # chain 1: CAB squeeze conv -> fold
-                    if w["sweep"]:
-                        ops.cab_squeeze(w["n"], fo["sq"][0], fo["sq"][1], w["c1"], w["colsum1"], B=B, H=H, W=W, C_=C, ldx=ldc, dtype=dt)
+                    # The critical chain — ESC weight kernel -> 13x13 conv -> tail — stays on ONE stream: every hop between
+                    # streams costs an event wait of ~12 us on this runtime (kernel trace: 2 hops per block = 0.9 ms per
+                    # frame when the 13x13 conv sat on the side stream).  The CAB squeeze conv and its fold are shorter and
+                    # go to the side stream (HAT_ESC_SIDE=1: the round-2 arrangement, for A/B).
+                    def squeeze_chain():
+                        if w["sweep"]:
+                            ops.cab_squeeze(w["n"], fo["sq"][0], fo["sq"][1], w["c1"], w["colsum1"], B=B, H=H, W=W, C_=C, ldx=ldc, dtype=dt)
+                        else:
+                            ops.conv(hb["cab0"], w["n"], w["c1"], **geo, ldx=ldc, ldo=8, act=ACT_GELU, n_store=8, colsum=w["colsum1"])
+                        ops.cab_fold(w["c1"], w["colsum1"], w["tiles1"], hb["cab0"].npad, fo["w2"], fo["b2"], hb["eca_w"],
+                                     hb["eca_w"].numel(), fo["ba"], float(cfg["conv_scale"]), w["scale"], w["wf"], w["bias_b"],
+                                     w["eca_tmp"], B=B, H=H, W=W, C_=C, mid=mid, dtype=dt)
+                    if os.environ.get("HAT_ESC_SIDE") == "1":
+                        self._esc_w(esc, w, B, H, W, nblk)
+                        s1.wait_stream(s0)                              # n and the 13x13 weights are ready
+                        with torch.cuda.stream(s1):                     # chain 2: 13x13 conv
+                            self._esc_conv(esc, w, w["n"], B, H, W, n16=(w["n16"] if have_n16 else None))
+                        squeeze_chain()
                     else:
-                        ops.conv(hb["cab0"], w["n"], w["c1"], **geo, ldx=ldc, ldo=8, act=ACT_GELU, n_store=8, colsum=w["colsum1"])
-                    ops.cab_fold(w["c1"], w["colsum1"], w["tiles1"], hb["cab0"].npad, fo["w2"], fo["b2"], hb["eca_w"],
-                                 hb["eca_w"].numel(), fo["ba"], float(cfg["conv_scale"]), w["scale"], w["wf"], w["bias_b"],
-                                 w["eca_tmp"], B=B, H=H, W=W, C_=C, mid=mid, dtype=dt)
-                    s0.wait_stream(s1)                              # y16 is ready
+                        s1.wait_stream(s0)                              # n is ready
+                        with torch.cuda.stream(s1):
+                            squeeze_chain()
+                        self._esc_w(esc, w, B, H, W, nblk)
+                        self._esc_conv(esc, w, w["n"], B, H, W, n16=(w["n16"] if have_n16 else None))
+                    s0.wait_stream(s1)                              # both chains are done
                     if hb.get("tail"):   # (also the faster choice on small frames: 64x64 HAT-S 3.97 vs 6.19 ms per forward)
                         # aggregation + folded CAB + residuals + the whole FFN in ONE launch: tB never exists in HBM
                         if i + 1 < len(L["habs"]):

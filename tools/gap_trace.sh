@@ -1,0 +1,29 @@
+#!/bin/bash
+# kernel trace of a few frames; prints the idle time between consecutive tail-kernel launches of a frame
+set -o pipefail
+R=$(pwd); export TMPDIR=/tmp; cd /tmp
+rm -rf $R/gpurun_out/gaptrace
+( cd $R && timeout -k 10 400 rocprofv3 --kernel-trace --output-format csv -d gpurun_out/gaptrace -- python3 bench.py --steps 3 --warmup 2 --cpu-crop 0 --no-f32-path --no-kernel-profile > gpurun_out/gaptrace.json 2> gpurun_out/gaptrace.err ) || { tail -5 $R/gpurun_out/gaptrace.err; exit 1; }
+cd $R
+python - <<'PY'
+import csv, glob
+f = glob.glob("gpurun_out/gaptrace/*/*kernel_trace.csv")[0]
+rows = list(csv.DictReader(open(f)))
+rows.sort(key=lambda r: int(r["Start_Timestamp"]))
+tails = [r for r in rows if "ffn2_kernel" in r["Kernel_Name"]]
+tails = tails[-36 * 2:]          # last two frames
+gaps, between = [], {}
+for a, b in zip(tails[:-1], tails[1:]):
+    g = (int(b["Start_Timestamp"]) - int(a["End_Timestamp"])) / 1e3
+    gaps.append(g)
+gaps_hab = sorted(g for g in gaps if g < 1000)
+print("tail->tail gap inside a group (us): median %.1f  p10 %.1f  p90 %.1f  n=%d" % (gaps_hab[len(gaps_hab)//2], gaps_hab[len(gaps_hab)//10], gaps_hab[len(gaps_hab)*9//10], len(gaps_hab)))
+# what runs in a typical gap
+a, b = tails[3], tails[4]
+t0 = int(a["End_Timestamp"])
+for r in rows:
+    s, e = int(r["Start_Timestamp"]), int(r["End_Timestamp"])
+    if s >= int(a["Start_Timestamp"]) and s <= int(b["Start_Timestamp"]):
+        print("  %-50s start %+8.1f us  dur %7.1f us" % (r["Kernel_Name"][:50], (s - t0) / 1e3, (e - s) / 1e3))
+PY
+rm -rf gpurun_out/gaptrace
