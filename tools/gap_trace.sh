@@ -25,5 +25,19 @@ for r in rows:
     s, e = int(r["Start_Timestamp"]), int(r["End_Timestamp"])
     if s >= int(a["Start_Timestamp"]) and s <= int(b["Start_Timestamp"]):
         print("  %-50s start %+8.1f us  dur %7.1f us" % (r["Kernel_Name"][:50], (s - t0) / 1e3, (e - s) / 1e3))
+# idle time of the last frame: union of kernel intervals between the first kernel after the previous frame's last tail ... crude: last frame = from
+# the 36th-last tail's predecessor conv_first to the end
+first = tails[-36]
+fs = max(i for i, r in enumerate(rows) if int(r["Start_Timestamp"]) < int(first["Start_Timestamp"]) and "conv" in r["Kernel_Name"] and "Li1E" in r["Kernel_Name"]) if any("Li1E" in r["Kernel_Name"] for r in rows) else rows.index(first)
+fr = rows[fs:]
+cur_end, idle, gaps = int(fr[0]["Start_Timestamp"]), 0, []
+for r in fr:
+    s, e = int(r["Start_Timestamp"]), int(r["End_Timestamp"])
+    if s > cur_end:
+        idle += s - cur_end
+        gaps.append(((s - cur_end) / 1e3, r["Kernel_Name"][:40]))
+    cur_end = max(cur_end, e)
+span = (cur_end - int(fr[0]["Start_Timestamp"])) / 1e6
+print("last frame: span %.2f ms, no kernel running for %.2f ms in %d gaps; largest:" % (span, idle / 1e6, len(gaps)), sorted(gaps, reverse=True)[:8])
 PY
 rm -rf gpurun_out/gaptrace
