@@ -42,8 +42,7 @@ __host__ inline bool conv_pick(const HatConvDesc& d, TileCfg* out, size_t* lds) 
     // workgroup's load / store phases overlap the other's MFMA phase — only when the weight slice is cheap to
     // re-stream per tile (smaller tiles re-read it more often); otherwise the largest tile that fits
     const size_t wbytes = (size_t)d.nt * 16 * d.ksize * d.ksize * ((d.Cin + 7) & ~7) * es;
-    static const bool two_wg = getenv("HAT_CONV_2WG") != nullptr;   // (experiment switch)
-    for (int pass = (wbytes <= 65536 || two_wg ? 0 : 1); pass < 2; ++pass) {
+    for (int pass = (wbytes <= 65536 ? 0 : 1); pass < 2; ++pass) {
         const size_t limit = pass == 0 ? HAT_LDS_MAX / 2 : HAT_LDS_MAX;
         for (int i = 0; i < 3; ++i) {
             const int rows = cands[i].waves * cands[i].pt;
@@ -57,7 +56,7 @@ __host__ inline bool conv_pick(const HatConvDesc& d, TileCfg* out, size_t* lds) 
 }
 
 template <typename T, int WAVES, int PT, int NT>
-__global__ __launch_bounds__(WAVES * 64, WAVES == 4 ? 2 : 1) void conv_kernel(const HatConvDesc d) {
+__global__ __launch_bounds__(WAVES * 64) void conv_kernel(const HatConvDesc d) {
     using M = MT<T>;
     constexpr int NTHR = WAVES * 64;
     constexpr int TROWS = WAVES * PT;
