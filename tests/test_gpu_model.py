@@ -225,6 +225,24 @@ def test_hatx_live_shapes_ocab_interior_windows_vs_reference_golden(mode):
     assert err <= 2e-4, f"interior windows vs reference: {err:.3e}"
 
 
+def test_fused_launches_agree_with_the_unfused_sequence(monkeypatch):
+    """The late round-2 fusions of the HAT-S path (hat_ocab_mlp, hat_ocab_qkv, LayerNorm in the group conv's epilogue, bf16
+    rows into the group conv, both pre-tail chains' stream assignment) against the launch sequence they replace, same weights,
+    a batch of two 48 x 80 frames (ragged against every tile size).  The two sequences round to bf16 at the same places but
+    accumulate in different orders; a flipped bf16 ulp is then amplified by 6 groups of blocks, so they agree the way two bf16
+    runs do (measured 47 dB; the bf16 path's bar against the fp32 reference is 40 dB), not bit for bit."""
+    dev = _dev()
+    x = synth.synth_input(X_SEED, (2, 3, 48, 80)).to(dev)
+    y_fused = build_net("HAT-S_x4", "bf16", dev)(x).float().cpu()
+    for k in ("HAT_NO_OCAB_MLP", "HAT_NO_OCAB_QKV", "HAT_NO_CONV_LN", "HAT_NO_BF16_CONV_IN"):
+        monkeypatch.setenv(k, "1")
+    monkeypatch.setenv("HAT_ESC_SIDE", "1")
+    y_plain = build_net("HAT-S_x4", "bf16", dev)(x).float().cpu()
+    torch.cuda.synchronize()
+    assert torch.isfinite(y_fused).all()
+    assert O.psnr_float(y_fused, y_plain) >= 44.0, O.psnr_float(y_fused, y_plain)
+
+
 @pytest.mark.parametrize("dtype", ["f32", "bf16"])
 def test_cfg1_hats_x2_64_vs_reference_golden(dtype):
     """BASELINE config 1: HAT-S x2 on a 3x64x64 LR tile."""
