@@ -251,6 +251,8 @@ class HAT(nn.Module):
         self._engine = None
         self._engine_key = None
         self._wver = 0   # bumped whenever the parameters may have changed (load_state_dict, .to()/.cuda()/..., explicit)
+        self._plist = None
+        self.register_load_state_dict_post_hook(HAT._post_load_hook)
         # extra (non-reference) switch: replay the forward as a HIP graph (also HAT_GRAPH=1 in the environment)
         self.use_graph = bool(kwargs.get("use_graph", False)) or os.environ.get("HAT_GRAPH") == "1"
         self._graphs, self._graph_engine = collections.OrderedDict(), None
@@ -279,27 +281,38 @@ class HAT(nn.Module):
         self._engine = None
         return self
 
-    # The engine holds PACKED copies of the parameters.  It is rebuilt when the weights version changes: the version is
-    # bumped by every bulk path that rewrites parameters — load_state_dict, and _apply (.to / .cuda / .float / ...) —
-    # instead of walking ~900 parameters on every forward (that walk alone was ~1 ms, a fifth of a 64x64 forward).
-    # Code that edits parameter tensors in place must call `mark_weights_changed()` (HAT_STRICT_WEIGHTS=1 restores the
-    # per-forward walk over (data_ptr, _version) for debugging).
+    # The engine holds PACKED copies of the parameters.  It is rebuilt when the weights key changes.  The key is cheap
+    # (a walk over data_ptr of ~900 parameters on every forward was ~1.5 ms, a third of a 64x64 forward) and has two parts:
+    #   * `_wver`, bumped by every bulk path that rewrites parameters: a load_state_dict POST HOOK (fires for this module
+    #     also when the call was made on a parent / wrapper — nn.DataParallel(net), nn.Sequential(net), a user container —
+    #     where torch recurses through _load_from_state_dict and never calls the child's load_state_dict), `_apply`
+    #     (.to / .cuda / .float / ...) and `mark_weights_changed()`;
+    #   * the sum of `p._version` over a cached parameter list (~0.1 ms for HAT-S's 910 parameters): catches every in-place edit autograd sees —
+    #     optimizer steps, `p.copy_()`, `p.mul_()` under no_grad.
+    # What this cannot see: an edit made through `p.data` (`p.data.mul_(d)`: `.data` has its own version counter by design,
+    # e.g. BasicSR's EMA update) and a parameter OBJECT replaced on a submodule (`net.conv_first.weight = nn.Parameter(..)`):
+    # such code must call `mark_weights_changed()` (the walk that would find them costs 1.5 ms).  HAT_STRICT_WEIGHTS=1 restores the
+    # full per-forward walk over (data_ptr, _version) for debugging.
     def mark_weights_changed(self):
         self._wver += 1
         return self
 
-    def load_state_dict(self, *args, **kwargs):
-        r = super().load_state_dict(*args, **kwargs)
-        self._wver += 1
-        return r
+    @staticmethod
+    def _post_load_hook(module, incompatible_keys):
+        module._wver = getattr(module, "_wver", 0) + 1
 
     def _apply(self, fn, *args, **kwargs):
         r = super()._apply(fn, *args, **kwargs)
         self._wver = getattr(self, "_wver", 0) + 1
+        self._plist = None
         return r
 
     def _weights_key(self, device):
-        key = (str(device), self.compute_dtype, self._wver)
+        pl = getattr(self, "_plist", None)
+        if pl is None or self._plist_wver != self._wver:
+            pl = self._plist = list(self.parameters())
+            self._plist_wver = self._wver
+        key = (str(device), self.compute_dtype, self._wver, sum(p._version for p in pl))
         if os.environ.get("HAT_STRICT_WEIGHTS") == "1":
             key += tuple((p.data_ptr(), p._version) for p in self.parameters())
         return key

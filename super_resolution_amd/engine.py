@@ -538,11 +538,13 @@ class HATEngine:
                     mkw = dict(m_in=w["m2"], ldm_in=w["m2"].shape[2]) if pre_ln else {}
                     if gap_c > 16:   # (the fused kernels pool at most 16 channels: a wider ESC gets its LayerNorm + pool from hat_layernorm)
                         ops.ffn(hb["ffn"], tB, tC, hb["n2"][0], hb["n2"][1], B=B, H=H, W=W, dtype=dt, **mkw)
-                        t, have_n = tC, False
+                        t, have_n, have_n16 = tC, False, False
                     else:
                         ops.ffn(hb["ffn"], tB, tC, hb["n2"][0], hb["n2"][1], B=B, H=H, W=W, dtype=dt, ln1=nxt, n_out=w["n"],
                                 ldn=ldc, gap_out=w["gap"], gap_c=gap_c, **mkw)
-                        t, have_n, nblk = tC, True, ops.ffn_tiles(hb["ffn"], H, W, dt)
+                        # (hat_ffn / hat_ffn2 emit the LayerNorm rows only: w["n16"] still holds an OLDER block's compact copy —
+                        # the group conv's or a fused tail's — and must not be handed to the next 13x13 conv)
+                        t, have_n, have_n16, nblk = tC, True, False, ops.ffn_tiles(hb["ffn"], H, W, dt)
                 else:
                     ln(tB, w["n"], hb["n2"])
                     hid2 = hb["fc1"].nout
@@ -554,7 +556,7 @@ class HATEngine:
                         ops.dwconv_gate(w["u"], hb["dw_w"], hb["dw_b"], w["g"], B=B, H=H, W=W, hid=hid2 // 2, ldu=w["u"].shape[2],
                                         ldo=w["g"].shape[2], dtype=dt)
                     self._run_lin(hb["fc2"], w["g"], tB, **geo, ldx=w["g"].shape[2], ldo=C, out_mode=O_NHWC_F32, r1=tB, ldr1=C)
-                    t, have_n = tB, False
+                    t, have_n, have_n16 = tB, False, False
             to_conv = (L["conv"] is not None and dt == ops.HAT_BF16 and ldc == C and L["ocab"]["mlp2"].frag
                        and not os.environ.get("HAT_NO_BF16_CONV_IN"))
             tout = run_ocab(L, t, have_n, nblk, as_conv_input=to_conv)

@@ -243,6 +243,26 @@ def test_fused_launches_agree_with_the_unfused_sequence(monkeypatch):
     assert O.psnr_float(y_fused, y_plain) >= 44.0, O.psnr_float(y_fused, y_plain)
 
 
+@pytest.mark.parametrize("switch", ["HAT_NO_HAB_TAIL", "HAT_FFN_V1"])
+def test_unfused_tail_switches_keep_the_13x13_conv_on_fresh_rows(monkeypatch, switch):
+    """Round-2 advisor finding: with the fused tail off (HAT_NO_HAB_TAIL=1) or the first-generation FFN kernel (HAT_FFN_V1=1)
+    and the group conv's LayerNorm epilogue ON, hat_ffn / hat_ffn2 emit the next LayerNorm rows but no compact 16-channel
+    copy — the engine must then not hand the group conv's stale copy to the next block's 13x13 conv.  Held against the
+    reference golden at the bf16 bar and against the default sequence (two bf16 runs: >= 44 dB)."""
+    dev = _dev()
+    g = golden("summary_HAT-S_x4_64.npz")
+    x = synth.synth_input(X_SEED, tuple(int(v) for v in g["x_shape"])).to(dev)
+    y_def = build_net("HAT-S_x4", "bf16", dev)(x).float().cpu()
+    monkeypatch.setenv(switch, "1")
+    y_sw = build_net("HAT-S_x4", "bf16", dev)(x).float().cpu()
+    torch.cuda.synchronize()
+    assert torch.isfinite(y_sw).all()
+    assert O.psnr_float(y_sw, y_def) >= 44.0, O.psnr_float(y_sw, y_def)
+    for k in ("tl", "br", "ce"):
+        a, b, c = (int(v) for v in g["pos_" + k])
+        assert_close(y_sw[..., a:a + c, b:b + c], torch.as_tensor(g["crop_" + k]), "bf16", f"HAT-S x4 64x64 with {switch}=1, crop {k}")
+
+
 @pytest.mark.parametrize("dtype", ["f32", "bf16"])
 def test_cfg1_hats_x2_64_vs_reference_golden(dtype):
     """BASELINE config 1: HAT-S x2 on a 3x64x64 LR tile."""

@@ -69,6 +69,27 @@ def test_weights_version_bumps_on_bulk_parameter_changes():
     assert net._weights_key("cuda:0")[1] == "f32"
 
 
+def test_weights_version_sees_wrapper_loads_and_in_place_edits():
+    """The two cases the round-2 key missed: load_state_dict called on a PARENT (torch recurses through
+    _load_from_state_dict and never calls the child's load_state_dict: nn.DataParallel, nn.Sequential, user containers),
+    and in-place parameter edits that autograd's version counter sees (optimizer steps, p.copy_ / p.mul_ under no_grad)."""
+    net = build_network(dict(type="HAT", **META["cfgs"]["tiny_x2"])).eval()
+    k = net._weights_key("cuda:0")
+    for wrap in (torch.nn.Sequential(net), torch.nn.DataParallel(net), torch.nn.ModuleDict({"g": net})):
+        wrap.load_state_dict(wrap.state_dict())
+        k, prev = net._weights_key("cuda:0"), k
+        assert k != prev, type(wrap).__name__
+    with torch.no_grad():
+        net.layers[0].residual_group.blocks[0].mlp.fc1.weight.mul_(1.5)
+    k, prev = net._weights_key("cuda:0"), k
+    assert k != prev
+    opt = torch.optim.SGD(net.parameters(), lr=0.1)
+    net.conv_first.weight.grad = torch.ones_like(net.conv_first.weight)
+    opt.step()
+    assert net._weights_key("cuda:0") != k
+    assert net._weights_key("cuda:0") == net._weights_key("cuda:0")
+
+
 def test_paired_dataset_crops_gt_to_lq_times_scale(tmp_path):
     """paired_image_dataset.py:92-95: in the test phase GT is cut to lq.shape * scale (benchmark GTs are often a few
     pixels larger), instead of failing the shape check of the metrics."""
