@@ -26,7 +26,9 @@
 extern "C" {
 #endif
 
-#define HAT_ABI_VERSION 1
+/* bumped whenever a descriptor layout, a packed-weight layout or the entry-point table changes (2: round 3 — HatConvDesc /
+ * HatFfnDesc grew in round 2 without a bump; hat_hab_tail3 and its packing; plan files carry the version) */
+#define HAT_ABI_VERSION 2
 
 enum { HAT_F32 = 0, HAT_BF16 = 1 };
 enum { HAT_EINVAL = -1, HAT_ELDS = -2, HAT_EUNSUPPORTED = -3 };
@@ -422,6 +424,20 @@ typedef struct HatHabTailDesc {
     int32_t ldn_in;
 } HatHabTailDesc;
 int hat_hab_tail(const HatHabTailDesc* d, void* stream);
+
+/*
+ * Third generation of the same launch (same HatHabTailDesc, same arithmetic, tiles, outputs and rounding points as
+ * hat_hab_tail; replaces the same reference lines).  LayerNorm2(tB) of the haloed tile stays in the REGISTERS of the wave
+ * that computed it (fc1 B fragments), and the weights of the current 32 (+32 gate) hidden units are copied into LDS once
+ * per workgroup by LDS-DMA and shared by its four waves, instead of every wave streaming its own fragments through L1/L2
+ * (344 KB of weights per 8 x 16 tile instead of 1 460 KB).  Different packing of the three per-chunk records:
+ *   w1f [chunk][4][5][64 lanes][8] bf16 : as for hat_ffn2, but K = 144 + the fc1 BIAS as column k = 144 (the kernel keeps
+ *                                         a 1.0 in k-slot 144 of every pixel inside the image and 0 outside: a pixel the
+ *                                         depthwise conv must see as zero padding gets U = 0 exactly, hat_arch.py:112-114)
+ *   dww [chunk][1024] fp16              : hat_ffn2's 640-element record zero padded to 2 KiB (two whole LDS-DMA pieces)
+ *   w2f [chunk][9][64 lanes][8] fp16    : as for hat_ffn2.   b1 and dwb are not read.
+ */
+int hat_hab_tail3(const HatHabTailDesc* d, void* stream);
 
 /*
  * Forward plans — the whole network behind three calls, for hosts without Python (SURVEY §8b's hat_forward(handle ...)).

@@ -12,6 +12,7 @@ import threading
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("HAT_MI355X_LIB") or os.path.join(_HERE, "libhat_mi355x.so")  # env override: A/B builds
 
+ABI_VERSION = 2   # == HAT_ABI_VERSION of include/hat_mi355x.h: bump both whenever a descriptor or packing changes
 HAT_F32, HAT_BF16 = 0, 1
 ACT_NONE, ACT_GELU, ACT_LRELU = 0, 1, 2
 X_NHWC_T, X_NHWC_F32, X_NCHW_F32_MEAN = 0, 1, 2
@@ -111,6 +112,7 @@ SIGNATURES = {
     "hat_ffn": (C.c_int, [C.POINTER(HatFfnDesc), C.c_void_p]),
     "hat_ffn2": (C.c_int, [C.POINTER(HatFfnDesc), C.c_void_p]),
     "hat_hab_tail": (C.c_int, [C.POINTER(HatHabTailDesc), C.c_void_p]),
+    "hat_hab_tail3": (C.c_int, [C.POINTER(HatHabTailDesc), C.c_void_p]),
     "hat_plan_load": (C.c_int, [C.c_char_p, C.POINTER(C.c_void_p)]),
     "hat_plan_info": (C.c_int, [C.c_void_p, C.POINTER(C.c_int32), C.POINTER(C.c_int64), C.POINTER(C.c_int64)]),
     "hat_plan_forward": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
@@ -171,8 +173,9 @@ def load():
                 raise RuntimeError(f"{LIB_PATH} does not export `{name}` (stale build?)")
             fn.restype = res
             fn.argtypes = args
-        if lib.hat_abi_version() != 1:
-            raise RuntimeError(f"ABI version mismatch: library {lib.hat_abi_version()}, binding 1")
+        if lib.hat_abi_version() != ABI_VERSION:
+            raise RuntimeError(f"ABI version mismatch: library {lib.hat_abi_version()}, binding {ABI_VERSION} (stale or overridden "
+                               f"{LIB_PATH}? rebuild with `python -m super_resolution_amd.build`)")
         _lib = lib
     return _lib
 

@@ -87,7 +87,7 @@ __global__ __launch_bounds__(256, 2) void ffn2_kernel(const HatFfnDesc d, const 
     // zero-pads u AFTER the fc1 bias (hat_arch.py:112-114), and the bias enters as the MFMA C operand.
     const bool edge = x0 == 0 || y0 == 0 || x0 + 16 >= W || y0 + F2_ROWS >= H;
 
-    long long tph[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    long long tph[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
     long long tlast = 0;
     auto stamp = [&](int slot) {
         if constexpr (DBG & 64) {
@@ -164,7 +164,9 @@ __global__ __launch_bounds__(256, 2) void ffn2_kernel(const HatFfnDesc d, const 
                 accx[nt] = *reinterpret_cast<const f32x4*>(tin + (size_t)pix[2] * C + nt * 16 + 4 * g) + bb;
             }
         }
+        stamp(8);
         __syncthreads();   // (drains vmcnt: the LDS-DMA copies of every wave have landed)
+        stamp(9);
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) {
 #pragma unroll
@@ -182,7 +184,9 @@ __global__ __launch_bounds__(256, 2) void ffn2_kernel(const HatFfnDesc d, const 
             gmv[nt] = *reinterpret_cast<const f32x4*>(d.ln_g + nt * 16 + 4 * g);
             btv[nt] = *reinterpret_cast<const f32x4*>(d.ln_b + nt * 16 + 4 * g);
         }
+        stamp(10);
         __syncthreads();   // every wave is done with the weights: Ms may be written
+        stamp(11);
         // LayerNorm2 (fp32 statistics over the 4 lane groups of a pixel) -> bf16 rows of Ms
 #pragma unroll
         for (int t = 0; t < 3; ++t) {
@@ -543,7 +547,7 @@ __global__ __launch_bounds__(256, 2) void ffn2_kernel(const HatFfnDesc d, const 
         stamp(7);
         if (lane == 0) {
             const size_t wg = ((size_t)blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;
-            for (int i = 0; i < 8; ++i) d.gap_out[(wg * F2_WAVES + wave) * 8 + i] = (float)tph[i];
+            for (int i = 0; i < 12; ++i) d.gap_out[(wg * F2_WAVES + wave) * 12 + i] = (float)tph[i];
         }
         return;
     }

@@ -354,9 +354,9 @@ __global__ __launch_bounds__(256) void cab_fold_kernel(const HatCabFoldDesc d) {
     T* wf = reinterpret_cast<T*>(d.wf) + (size_t)b * nt * 3 * 512;
     constexpr int FU = 9;  // elements per thread per batch
     for (int i0 = tid; i0 < nt * 3 * 512; i0 += 256 * FU) {
-        float wv[FU];
+        float wv[FU], bi[FU], b2v[FU];
         bool ok[FU];
-        int cov[FU];
+        int cov[FU], bsel[FU];
 #pragma unroll
         for (int u = 0; u < FU; ++u) {
             const int i = min(i0 + u * 256, nt * 3 * 512 - 1);
@@ -364,13 +364,22 @@ __global__ __launch_bounds__(256) void cab_fold_kernel(const HatCabFoldDesc d) {
             const int co = t * 16 + (lane & 15), k = 32 * ks + 8 * (lane >> 4) + j;
             const int tap = k >> 3, ci = k & 7;
             ok[u] = co < C && tap < 9 && ci < mid;
+            // k = 72, 73 (the first two of the 24 unused k-slots): the folded bias itself, split into a bf16 head and the bf16
+            // of its remainder.  hat_hab_tail3 multiplies these two slots by 1.0 (its accumulators then start from the
+            // residual alone); every other consumer reads zeros there (their im2col has no tap 9), so the columns are inert.
+            bsel[u] = (co < C && tap == 9 && ci < 2) ? 1 + ci : 0;
             cov[u] = min(co, C - 1);
             wv[u] = d.w2[((size_t)cov[u] * mid + min(ci, mid - 1)) * 9 + min(tap, 8)];
+            bi[u] = d.bias_in[cov[u]];
+            b2v[u] = d.b2[cov[u]];
         }
 #pragma unroll
         for (int u = 0; u < FU; ++u) {
             const int i = i0 + u * 256;
-            if (i < nt * 3 * 512) wf[i] = to_T<T>(ok[u] ? scl[cov[u]] * wv[u] : 0.f);
+            const float bfull = bi[u] + scl[cov[u]] * b2v[u];
+            const float bhead = to_f(to_T<T>(bfull));
+            const float v = bsel[u] == 1 ? bfull : (bsel[u] == 2 ? bfull - bhead : (ok[u] ? scl[cov[u]] * wv[u] : 0.f));
+            if (i < nt * 3 * 512) wf[i] = to_T<T>(v);
         }
     }
 }

@@ -41,6 +41,7 @@ struct hat_plan {
     int32_t dims[8];   // B, Cin, H, W, scale, Cout, dtype, reserved
     std::vector<Buf> bufs;
     std::vector<Call> calls;
+    int device = -1;   // the device the buffers were allocated on (hat_plan_forward refuses to launch on another one)
 };
 
 namespace {
@@ -55,7 +56,7 @@ struct Reader {
 // function ids: the order of this table is the file format (super_resolution_amd/plan.py FN_IDS mirrors it)
 const char* const FN_NAMES[] = {"hat_conv", "hat_linear", "hat_conv3x3_small", "hat_cab_fold", "hat_aggr_cab", "hat_ffn", "hat_ffn2",
                                 "hat_hab_tail", "hat_layernorm", "hat_esc_weights", "hat_eca_scale", "hat_dwconv_gate", "hat_sgfn_gate",
-                                "hat_ocab_attention", "hat_window_attention", "hat_cab_squeeze", "hat_conv3x3_to_planes", "hat_add_f32", "hat_esc_conv13", "hat_ocab_keybias", "hat_ocab_attention_kb", "hat_ocab_mlp", "hat_ocab_qkv"};
+                                "hat_ocab_attention", "hat_window_attention", "hat_cab_squeeze", "hat_conv3x3_to_planes", "hat_add_f32", "hat_esc_conv13", "hat_ocab_keybias", "hat_ocab_attention_kb", "hat_ocab_mlp", "hat_ocab_qkv", "hat_hab_tail3"};
 constexpr uint32_t N_FN = sizeof(FN_NAMES) / sizeof(FN_NAMES[0]);
 
 struct Resolved {   // argument values of one call with the pointers patched
@@ -149,6 +150,7 @@ int dispatch(Resolved& r) {
                            : HAT_EINVAL;
         case 21: return n == 2 ? hat_ocab_mlp((const HatMlpDesc*)r.P(0), r.P(1)) : HAT_EINVAL;
         case 22: return n == 2 ? hat_ocab_qkv((const HatMlpDesc*)r.P(0), r.P(1)) : HAT_EINVAL;
+        case 23: return n == 2 ? hat_hab_tail3((const HatHabTailDesc*)r.P(0), r.P(1)) : HAT_EINVAL;
         default: return HAT_EUNSUPPORTED;
     }
 }
@@ -162,9 +164,34 @@ extern "C" void hat_plan_free(hat_plan* p) {
     delete p;
 }
 
+static int plan_load_impl(const char* path, hat_plan** out);
+
+// The file is untrusted input: every count, size, buffer index and offset is checked against what it indexes, and nothing
+// thrown by the containers (a corrupt size -> std::bad_alloc / length_error) may cross the extern "C" boundary.
 extern "C" int hat_plan_load(const char* path, hat_plan** out) {
     if (!path || !out) return HAT_EINVAL;
     *out = nullptr;
+    try {
+        return plan_load_impl(path, out);
+    } catch (...) {
+        return HAT_EINVAL;
+    }
+}
+
+namespace {
+constexpr uint64_t MAX_BUF_BYTES = 1ull << 38;   // 256 GiB: above one MI355X's HBM
+// (buffer, offset) must point INTO the buffer (one-past-the-end is allowed for empty views)
+bool ptr_ok(const std::vector<Buf>& bufs, uint32_t buf, uint64_t off) {
+    if (buf == NULL_BUF) return true;
+    return buf < bufs.size() && off <= bufs[buf].nbytes;
+}
+struct PlanGuard {   // frees a half-built plan on every exit path, exceptions included
+    hat_plan* p;
+    ~PlanGuard() { if (p) hat_plan_free(p); }
+};
+}  // namespace
+
+static int plan_load_impl(const char* path, hat_plan** out) {
     FILE* f = fopen(path, "rb");
     if (!f) return HAT_EINVAL;
     Reader rd{f};
@@ -172,8 +199,12 @@ extern "C" int hat_plan_load(const char* path, hat_plan** out) {
     rd.bytes(magic, 8);
     if (!rd.ok || memcmp(magic, "HATPLAN1", 8) != 0) { fclose(f); return HAT_EINVAL; }
     const uint32_t version = rd.get<uint32_t>(), nbuf = rd.get<uint32_t>(), ncall = rd.get<uint32_t>(), nfn = rd.get<uint32_t>();
-    if (!rd.ok || version != 1 || nfn != N_FN) { fclose(f); return HAT_EUNSUPPORTED; }
+    // version = HAT_ABI_VERSION of the writer: the calls embed raw images of this header's descriptors
+    if (!rd.ok || version != HAT_ABI_VERSION || nfn != N_FN || nbuf > (1u << 20) || ncall > (1u << 24)) { fclose(f); return HAT_EUNSUPPORTED; }
     hat_plan* p = new hat_plan();
+    PlanGuard guard{p};
+    struct FileGuard { FILE* f; ~FileGuard() { if (f) fclose(f); } } fguard{f};
+    if (hipGetDevice(&p->device) != hipSuccess) return HAT_EINVAL;
     for (int i = 0; i < 8; ++i) p->dims[i] = rd.get<int32_t>();
     int rc = 0;
     for (uint32_t i = 0; i < nbuf && rd.ok && !rc; ++i) {
@@ -181,6 +212,7 @@ extern "C" int hat_plan_load(const char* path, hat_plan** out) {
         b.kind = rd.get<uint32_t>();
         (void)rd.get<uint32_t>();
         b.nbytes = rd.get<uint64_t>();
+        if (!rd.ok || b.kind > BUF_OUTPUT || b.nbytes > MAX_BUF_BYTES) { rc = HAT_EINVAL; break; }
         if (b.kind == BUF_CONST || b.kind == BUF_SCRATCH) {
             hipError_t e = hipMalloc(&b.dev, b.nbytes ? b.nbytes : 16);
             if (e != hipSuccess) { rc = (int)e; break; }
@@ -220,19 +252,19 @@ extern "C" int hat_plan_load(const char* path, hat_plan** out) {
                     fx.field_off = rd.get<uint32_t>();
                     fx.buf = rd.get<uint32_t>();
                     fx.off = rd.get<uint64_t>();
-                    if (fx.field_off + sizeof(void*) > nb || (fx.buf != NULL_BUF && fx.buf >= nbuf)) rc = HAT_EINVAL;
+                    if ((uint64_t)fx.field_off + sizeof(void*) > nb || !ptr_ok(p->bufs, fx.buf, fx.off)) rc = HAT_EINVAL;
                     a.fix.push_back(fx);
                 }
             } else if (a.tag != ARG_STREAM) rc = HAT_EINVAL;
-            if (a.tag == ARG_PTR && a.buf != NULL_BUF && a.buf >= nbuf) rc = HAT_EINVAL;
+            if (a.tag == ARG_PTR && !ptr_ok(p->bufs, a.buf, a.off)) rc = HAT_EINVAL;
             c.args.push_back(std::move(a));
         }
         p->calls.push_back(std::move(c));
     }
-    fclose(f);
     if (!rd.ok && !rc) rc = HAT_EINVAL;
     if (!rc) rc = (int)hipDeviceSynchronize();
-    if (rc) { hat_plan_free(p); return rc; }
+    if (rc) return rc;       // (the guards free the plan and close the file)
+    guard.p = nullptr;
     *out = p;
     return 0;
 }
@@ -252,6 +284,9 @@ extern "C" int hat_plan_info(const hat_plan* p, int32_t* dims8, int64_t* n_calls
 
 extern "C" int hat_plan_forward(const hat_plan* p, const float* x, float* y, void* stream) {
     if (!p || !x || !y) return HAT_EINVAL;
+    int dev = -1;
+    // the kernels launch on the CURRENT device: it must be the one the plan's buffers live on
+    if (hipGetDevice(&dev) != hipSuccess || dev != p->device) return HAT_EINVAL;
     for (const Call& c : p->calls) {
         Resolved r{p, &c, x, y, stream, {}};
         const int rc = dispatch(r);

@@ -177,6 +177,10 @@ class HATEngine:
                         hb["ffn"] = ops.pack_ffn(*fw, dt, dev)
                     hb["tail"] = ("fold" in hb and hb["esc"].pdim == 16 and ops.hab_tail_supported(hb["ffn"], hb["esc"].aggr, w2raw.shape[1], dt)
                                   and os.environ.get("HAT_NO_HAB_TAIL") != "1")
+                    # third-generation tail (activation-stationary fc1, weights shared through LDS): its own packing;
+                    # HAT_TAIL_V2=1 keeps hat_hab_tail for A/B runs
+                    if hb["tail"] and hb["ffn"].khalf == "v2" and os.environ.get("HAT_TAIL_V2") != "1":
+                        hb["ffn3"] = ops.pack_ffn3(*fw, *hb["n2"], dev)
                 L["habs"].append(hb)
             p = f"layers.{g}.residual_group.overlap_attn"
             d = C // heads
@@ -503,7 +507,7 @@ class HATEngine:
                         else:
                             nxt, gap_c = oc["n1"], (oc["esc"].pdim if "esc" in oc else 0)
                         tout = tB if t is not tB else tC
-                        ops.hab_tail(hb["ffn"], esc.aggr, t, tout, hb["n2"][0], hb["n2"][1], n=w["n"], ldn_in=ldc, y16=w["y16"],
+                        ops.hab_tail(hb.get("ffn3", hb["ffn"]), esc.aggr, t, tout, hb["n2"][0], hb["n2"][1], n=w["n"], ldn_in=ldc, y16=w["y16"],
                                      c1=w["c1"], wf=w["wf"], bias_b=w["bias_b"], B=B, H=H, W=W, dtype=dt, ln1=nxt, n_out=w["n2b"],
                                      ldn=ldc, gap_out=w["gap"], gap_c=gap_c, n16_out=(w["n16"] if self.use_n16 else None))
                         w["n"], w["n2b"] = w["n2b"], w["n"]      # the kernel reads n with a halo: its output n' is another buffer

@@ -543,6 +543,33 @@ def pack_ffn2(fc1_w, fc1_b, dw_w, dw_b, fc2_w, fc2_b, device) -> PackedFFN:
     return p
 
 
+def pack_ffn3(fc1_w, fc1_b, dw_w, dw_b, fc2_w, fc2_b, ln_g, ln_b, device) -> PackedFFN:
+    """GatedDconvFFN weights (hat_arch.py:99-104) + the affine part of the LayerNorm in front of them (norm2, hat_arch.py:237)
+    in hat_hab_tail3's layouts (include/hat_mi355x.h): hat_ffn2's, with
+      * LayerNorm2's gamma folded into the fc1 columns and W1 . beta into the fc1 bias (fc1(xhat * gamma + beta) =
+        (W1 diag(gamma)) xhat + (W1 beta + b1), exact in real arithmetic): the kernel normalises without an affine step;
+      * the fc1 bias as column k = 144 of the fc1 fragments;
+      * the depthwise record of a chunk zero padded to 2 KiB and the fc2 bias to 1 KiB (every record the kernel copies is then
+        a whole number of 1 KiB LDS-DMA pieces)."""
+    f = lambda t: t.detach().to(torch.float32).cpu()
+    W1, gam, bet = f(fc1_w), f(ln_g), f(ln_b)
+    p = pack_ffn2(W1 * gam[None, :], f(fc1_b) + W1 @ bet, dw_w, dw_b, fc2_w, fc2_b, device)
+    chunks = p.chunks
+    w1 = p.w1f.to("cpu").reshape(chunks, 4, 5, 64, 8).clone()
+    # element (chunk, tile, ks = 4, lane, j) holds k = 128 + 8 (lane >> 4) + j of fc1 row (tile, lane & 15): k = 144 <- the bias
+    lane = torch.arange(64)
+    b1 = p.b1.to("cpu").reshape(chunks, 4, 16)                      # pack_ffn2's b1c: the chunk's rows in fragment order
+    sel = (lane >> 4) == 2
+    w1[:, :, 4, sel, 0] = b1[:, :, lane[sel] & 15].to(torch.bfloat16)
+    dw = torch.zeros(chunks, 1024, dtype=torch.float16)
+    dw[:, :640] = p.dww.to("cpu").reshape(chunks, 640)
+    b2 = torch.zeros(256)
+    b2[:p.b2.numel()] = p.b2.to("cpu")
+    p.w1f, p.dww, p.b2 = w1.contiguous().to(device), dw.contiguous().to(device), b2.to(device)
+    p.khalf = "v3"
+    return p
+
+
 def _ffn_desc(pf: PackedFFN, B, H, W, dtype):
     d = HatFfnDesc()
     d.B, d.H, d.W, d.C, d.chunks, d.dtype = B, H, W, pf.C, pf.chunks, dtype
@@ -585,6 +612,8 @@ def ffn(pf: PackedFFN, t_in, t_out, ln_g, ln_b, *, B: int, H: int, W: int, dtype
     # (with m_in, LayerNorm2(t_in) arrives pre-computed as T rows: it replaces the haloed fp32 read; t_in is still read
     # once for the residual)
     nbytes = B * H * W * (4.0 * pf.C + 4.0 * pf.C + (es * ldn if ln1 is not None else 0) + (es * ldm_in if m_in is not None else 0))
+    if pf.khalf == "v3":
+        raise RuntimeError("a hat_hab_tail3-packed FFN has no stand-alone launch: pack with pack_ffn2 for hat_ffn2")
     if pf.khalf == "v2":
         _timed("ffn2_kernel", flops, lambda: _lib.check(lib.hat_ffn2(C.byref(d), _stream()), "hat_ffn2"), nbytes=nbytes)
         return
@@ -593,7 +622,7 @@ def ffn(pf: PackedFFN, t_in, t_out, ln_g, ln_b, *, B: int, H: int, W: int, dtype
 
 
 def hab_tail_supported(pf: PackedFFN, aggr: PackedConv, mid: int, dtype: int) -> bool:
-    return pf.khalf == "v2" and aggr.frag and aggr.nt == 9 and aggr.n_slices == 1 and aggr.kpad == 160 and mid <= 8 and dtype == HAT_BF16
+    return pf.khalf in ("v2", "v3") and aggr.frag and aggr.nt == 9 and aggr.n_slices == 1 and aggr.kpad == 160 and mid <= 8 and dtype == HAT_BF16
 
 
 def hab_tail(pf: PackedFFN, aggr: PackedConv, t_in, t_out, ln_g, ln_b, *, n, ldn_in: int, y16, c1, wf, bias_b, B: int, H: int,
@@ -610,6 +639,9 @@ def hab_tail(pf: PackedFFN, aggr: PackedConv, t_in, t_out, ln_g, ln_b, *, n, ldn
     # algorithmic HBM bytes per pixel: n (T), y16 (T x 16), c1 (T x 8), t (fp32) read once; t_out (fp32) and the next
     # block's LayerNorm output (T) written
     nbytes = B * H * W * (2.0 * ldn_in + 32 + 16 + 4.0 * pf.C + 4.0 * pf.C + (2 * ldn if ln1 is not None else 0))
+    if pf.khalf == "v3":
+        _timed("tail3_kernel", flops, lambda: _lib.check(lib.hat_hab_tail3(C.byref(h), _stream()), "hat_hab_tail3"), nbytes=nbytes)
+        return
     _timed("ffn2_kernel<aggr>", flops, lambda: _lib.check(lib.hat_hab_tail(C.byref(h), _stream()), "hat_hab_tail"), nbytes=nbytes)
 
 

@@ -23,6 +23,7 @@ import bisect
 import ctypes as C
 import os
 import struct
+import threading
 from typing import List, Tuple
 
 import torch
@@ -32,10 +33,11 @@ from . import _lib
 # function ids = index in this list (csrc/hat_plan.cpp FN_NAMES mirrors it)
 FN_IDS = ["hat_conv", "hat_linear", "hat_conv3x3_small", "hat_cab_fold", "hat_aggr_cab", "hat_ffn", "hat_ffn2", "hat_hab_tail",
           "hat_layernorm", "hat_esc_weights", "hat_eca_scale", "hat_dwconv_gate", "hat_sgfn_gate", "hat_ocab_attention",
-          "hat_window_attention", "hat_cab_squeeze", "hat_conv3x3_to_planes", "hat_add_f32", "hat_esc_conv13", "hat_ocab_keybias", "hat_ocab_attention_kb", "hat_ocab_mlp", "hat_ocab_qkv"]
+          "hat_window_attention", "hat_cab_squeeze", "hat_conv3x3_to_planes", "hat_add_f32", "hat_esc_conv13", "hat_ocab_keybias", "hat_ocab_attention_kb", "hat_ocab_mlp", "hat_ocab_qkv", "hat_hab_tail3"]
 ARG_INT, ARG_FLOAT, ARG_PTR, ARG_STRUCT, ARG_HOST, ARG_STREAM = range(6)
 BUF_CONST, BUF_SCRATCH, BUF_INPUT, BUF_OUTPUT = range(4)
 NULL_BUF = 0xFFFFFFFF
+_EXPORT_LOCK = threading.Lock()
 
 
 class _Recorder:
@@ -43,6 +45,7 @@ class _Recorder:
 
     def __init__(self, lib):
         self._lib, self.calls = lib, []
+        self._tid = threading.get_ident()    # only the exporting thread's launches belong to the plan
 
     def __getattr__(self, name):
         fn = getattr(self._lib, name)
@@ -50,7 +53,8 @@ class _Recorder:
             return fn      # queries (tile counts, plans): not launches
 
         def call(*args):
-            self.calls.append((name, [_snapshot(a) for a in args]))
+            if threading.get_ident() == self._tid:   # (another thread's forward passes through unrecorded)
+                self.calls.append((name, [_snapshot(a) for a in args]))
             return fn(*args)
         return call
 
@@ -108,6 +112,7 @@ def export_plan(net, x_shape: Tuple[int, int, int, int], path: str) -> dict:
     rec = _Recorder(real)
     prev_one = os.environ.get("HAT_ONE_STREAM")
     os.environ["HAT_ONE_STREAM"] = "1"          # the plan replays on one stream: record the launches in that order
+    _EXPORT_LOCK.acquire()                     # one export at a time: the recorder stands in for the process-wide library handle
     _lib._lib = rec
     try:
         with torch.no_grad():
@@ -115,6 +120,7 @@ def export_plan(net, x_shape: Tuple[int, int, int, int], path: str) -> dict:
         torch.cuda.synchronize(dev)
     finally:
         _lib._lib = real
+        _EXPORT_LOCK.release()
         if prev_one is None:
             os.environ.pop("HAT_ONE_STREAM", None)
         else:
@@ -156,7 +162,7 @@ def export_plan(net, x_shape: Tuple[int, int, int, int], path: str) -> dict:
                            f"or the output (a temporary allocated inside forward?)")
 
     out = bytearray()
-    out += b"HATPLAN1" + struct.pack("<4I", 1, len(bufs), len(rec.calls), len(FN_IDS))
+    out += b"HATPLAN1" + struct.pack("<4I", _lib.ABI_VERSION, len(bufs), len(rec.calls), len(FN_IDS))
     out += struct.pack("<8i", B, Cin, H, W, eng.scale, y.shape[1], eng.dtype, 0)
     for b in bufs:
         out += struct.pack("<IIQ", b["kind"], 0, b["nbytes"])

@@ -36,7 +36,7 @@ def test_library_exports_every_declared_symbol(lib_path):
     for n in names:
         assert getattr(lib, n, None) is not None, f"{n} is declared in include/hat_mi355x.h but not exported"
     loaded = _lib.load()
-    assert loaded.hat_abi_version() == 1
+    assert loaded.hat_abi_version() == 2
     assert loaded.hat_target_arch() == b"gfx950"
     assert loaded.hat_layernorm_blocks() > 0
 

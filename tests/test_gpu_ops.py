@@ -711,9 +711,11 @@ def test_esc_conv13_resident(geom):
     assert float((y.float() - y2.float()).abs().max()) <= 0.04 * max(1.0, float(y2.float().abs().max()))   # two bf16 roundings of the same sums
 
 
+@pytest.mark.parametrize("gen", ["v2", "v3"])
 @pytest.mark.parametrize("geom", [(2, 24, 40), (1, 19, 27), (1, 8, 16), (1, 35, 64)], ids=["B2_24x40", "ragged_19x27", "one_tile", "35x64"])
-def test_hab_tail_fused(geom):
-    """hat_hab_tail = hat_aggr_cab + hat_ffn2 in one launch (hat_arch.py:233-237, esc_arch.py:123): t + aggr([y16 | n[16:]]) +
+def test_hab_tail_fused(geom, gen):
+    """hat_hab_tail (v2) / hat_hab_tail3 (v3: activation-stationary fc1, LayerNorm2's affine folded into fc1 at pack time, bias
+    terms as k-slots) = hat_aggr_cab + hat_ffn2 in one launch (hat_arch.py:233-237, esc_arch.py:123): t + aggr([y16 | n[16:]]) +
     folded CAB, LayerNorm2, gated depthwise FFN, residual, next LayerNorm + GAP partials.  Checked against (a) the two-kernel
     sequence it replaces (same arithmetic, tB merely never leaves the chip: agreement to a few flipped bf16 roundings) and (b) an
     fp64 restatement, on interior and border tiles, ragged sizes and B = 2."""
@@ -767,14 +769,17 @@ def test_hab_tail_fused(geom):
     out2, n2, gap2 = torch.zeros_like(tB), torch.zeros(B, H * W, C, dtype=tdt, device=dev), torch.zeros(B, tiles, 16, device=dev)
     ops.ffn(pf, tB, out2, dv("n2.weight"), dv("n2.bias"), n_out=n2, gap_out=gap2, **kw)
     out1, n1, gap1 = torch.full_like(tB, 7.0), torch.zeros_like(n2), torch.zeros_like(gap2)
-    ops.hab_tail(pf, pw, td, out1, dv("n2.weight"), dv("n2.bias"), n=nd, ldn_in=C, y16=yd, c1=c1d, wf=wf, bias_b=bias_b,
+    pft = pf if gen == "v2" else ops.pack_ffn3(sd["m.fc1.weight"], sd["m.fc1.bias"], sd["m.dw.weight"], sd["m.dw.bias"], sd["m.fc2.weight"],
+                                               sd["m.fc2.bias"], sd["n2.weight"], sd["n2.bias"], dev)
+    ops.hab_tail(pft, pw, td, out1, dv("n2.weight"), dv("n2.bias"), n=nd, ldn_in=C, y16=yd, c1=c1d, wf=wf, bias_b=bias_b,
                  n_out=n1, gap_out=gap1, **kw)
     torch.cuda.synchronize()
     assert torch.isfinite(out1).all()
     d12 = float((out1 - out2).abs().max())
     # same arithmetic; fp32 round-off in tB may flip single bf16 roundings of LayerNorm2's output (an ulp is 0.4 %)
-    assert d12 <= 1e-3 * max(1.0, float(out2.abs().max())), f"fused vs two-kernel sequence: max-abs {d12:.3e}"
-    assert float((n1.float() - n2.float()).abs().max()) <= 0.04 and float((gap1 - gap2).abs().max()) <= 1e-2 * H * W / tiles
+    # (v3 rounds W1 * gamma to bf16 where the two-kernel sequence rounds W1 and LayerNorm2's output: two bf16 evaluations)
+    assert d12 <= (1e-3 if gen == "v2" else 2e-2) * max(1.0, float(out2.abs().max())), f"fused vs two-kernel sequence: max-abs {d12:.3e}"
+    assert float((n1.float() - n2.float()).abs().max()) <= (0.04 if gen == "v2" else 0.08) and float((gap1 - gap2).abs().max()) <= 1e-2 * H * W / tiles
     upd, upd_ref = out1.double().cpu() - tb, ref - tb
     rel = float((upd - upd_ref).norm() / upd_ref.norm())
     assert rel <= 1.2e-2, f"hab tail FFN update rel err {rel:.3e}"

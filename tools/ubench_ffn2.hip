@@ -58,16 +58,17 @@ int main() {
     if (getenv("UB_PHASES")) {
         run<0>(d, 200);
         const size_t nwg = (size_t)((W + 15) / 16) * ((H + 7) / 8);
-        float* ph; CK(hipMalloc(&ph, nwg * 4 * 8 * 4));
+        float* ph; CK(hipMalloc(&ph, nwg * 4 * 12 * 4));
         d.gap_out = ph;
         const bool ag = getenv("UB_AGGR") != nullptr;
         printf("instrumented run (%s) %.3f ms\n", ag ? "fused aggregation" : "plain", ag ? run<64, true>(d, 2) : run<64>(d, 2));
-        std::vector<float> hp(nwg * 4 * 8);
+        std::vector<float> hp(nwg * 4 * 12);
         CK(hipMemcpy(hp.data(), ph, hp.size() * 4, hipMemcpyDeviceToHost));
-        const char* names[8] = {"LN stage", "barrier after LN", "phase A (fc1)", "barrier after A", "phase B (dw, VALU)", "phase C (gate+fc2)", "barrier after C", "epilogue"};
-        double tot[8] = {0}; double all = 0;
-        for (size_t i = 0; i < nwg * 4; ++i) for (int k = 0; k < 8; ++k) { tot[k] += hp[i * 8 + k]; all += hp[i * 8 + k]; }
-        for (int k = 0; k < 8; ++k) printf("  %-22s %10.0f cycles/wave  (%.1f%%)\n", names[k], tot[k] / (nwg * 4), 100.0 * tot[k] / all);
+        const char* names[12] = {"LN stage (rest: LN + Ms)", "barrier after LN", "phase A (fc1)", "barrier after A", "phase B (dw, VALU)", "phase C (gate+fc2)", "barrier after C", "epilogue",
+                                 "s0: issue loads", "s0: wait loads+barrier", "s0: MFMA", "s0: barrier 2"};
+        double tot[12] = {0}; double all = 0;
+        for (size_t i = 0; i < nwg * 4; ++i) for (int k = 0; k < 12; ++k) { tot[k] += hp[i * 12 + k]; all += hp[i * 12 + k]; }
+        for (int k = 0; k < 12; ++k) printf("  %-22s %10.0f cycles/wave  (%.1f%%)\n", names[k], tot[k] / (nwg * 4), 100.0 * tot[k] / all);
         printf("  total %.0f cycles/wave\n", all / (nwg * 4));
         return 0;
     }
