@@ -151,6 +151,11 @@ typedef struct HatCabFoldDesc {
     float* tmp;              /* scratch [B][32][ldcs] */
     int32_t B, H, W, C, mid, ld1, tiles, ldcs, k, ld_scale, dtype;
     float conv_scale;
+    /* optional [B][72] fp32: the sums this kernel otherwise takes from c1 / c1_colsum, supplied by the caller — a frame that is
+     * sharded into row bands adds up its bands' hat_rect_sum results: [0,8) sums of c1's channels over the whole
+     * frame, [8,40) over its first row, last row, first column, last column, [40,72) its four corner pixels (top-left,
+     * top-right, bottom-left, bottom-right).  H, W are then the FULL frame's; c1, c1_colsum, tmp are not read. */
+    const float* stats;
 } HatCabFoldDesc;
 int hat_cab_fold(const HatCabFoldDesc* d, void* stream);
 
@@ -458,6 +463,19 @@ int hat_plan_load(const char* path, hat_plan** out);
 int hat_plan_info(const hat_plan* plan, int32_t* dims8, int64_t* n_calls, int64_t* device_bytes);
 int hat_plan_forward(const hat_plan* plan, const float* x, float* y, void* stream);
 void hat_plan_free(hat_plan* plan);
+
+/*
+ * Per-channel sums of a channel-last map over the pixel rectangle rows [r0, r1) x columns [c0, c1):
+ *     out[b][ch] = sum x[b][(r*W + c)*ld + ch],  ch < C (out[b][C..ldo) = 0),  x: T = bf16 / fp32, ld % 4 == 0 with zero pad channels
+ * — the global average pools of the path (ECA, hat_arch.py:73; ESC dynamic kernel, esc_arch.py:96,121) when a frame is sharded
+ * into row bands and every band contributes the sums of the rows it OWNS; the bands' vectors are then added
+ * (hat_add_f32 on one GPU, an RCCL all-reduce across GPUs) and fed to hat_esc_weights / hat_eca_scale as ONE block, to
+ * hat_cab_fold as `stats`.  Deterministic: fixed reduction order, cross-workgroup part in fp64.
+ * bstride: elements between samples; tmp: [B][64][256] fp32 scratch; counter: [B] uint32, zero before the first call
+ * (the kernel leaves it zero).
+ */
+int hat_rect_sum(const void* x, int32_t dtype, int32_t ld, int32_t C, int32_t W, int32_t r0, int32_t r1, int32_t c0, int32_t c1,
+                 int64_t bstride, int32_t B, float* out, int32_t ldo, float* tmp, uint32_t* counter, void* stream);
 
 int hat_abi_version(void);
 /* name of the architecture the code objects in this library were compiled for ("gfx950") */

@@ -83,7 +83,7 @@ class HatCabFoldDesc(C.Structure):
         ("bias_in", C.c_void_p), ("scale", C.c_void_p), ("wf", C.c_void_p), ("bias_out", C.c_void_p), ("tmp", C.c_void_p),
         ("B", C.c_int32), ("H", C.c_int32), ("W", C.c_int32), ("C", C.c_int32), ("mid", C.c_int32), ("ld1", C.c_int32),
         ("tiles", C.c_int32), ("ldcs", C.c_int32), ("k", C.c_int32), ("ld_scale", C.c_int32), ("dtype", C.c_int32),
-        ("conv_scale", C.c_float),
+        ("conv_scale", C.c_float), ("stats", C.c_void_p),
     ]
 
 
@@ -120,6 +120,8 @@ SIGNATURES = {
     "hat_layernorm_blocks": (C.c_int, []),
     "hat_layernorm": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int64,
                                 C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_void_p]),
+    "hat_rect_sum": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32,
+                               C.c_int64, C.c_int32, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p]),
     "hat_add_f32": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int64, C.c_int64, C.c_void_p]),
     "hat_esc_weights": (C.c_int, [C.c_void_p, C.c_int32, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                   C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_void_p]),

@@ -246,8 +246,12 @@ __global__ __launch_bounds__(256) void cab_fold_kernel(const HatCabFoldDesc d) {
     const int tid = threadIdx.x, b = blockIdx.x;
     const int H = d.H, W = d.W, C = d.C, mid = d.mid;
     const T* c1 = reinterpret_cast<const T*>(d.c1) + (size_t)b * H * W * d.ld1;
+    const float* st = d.stats ? d.stats + (size_t)b * 72 : nullptr;   // (uniform) sums supplied by the caller: band-sharded frames
+    if (st != nullptr) {
+        if (tid < 32) bord[tid >> 3][tid & 7] = st[8 + tid];
+        __syncthreads();
+    } else {
     // border sums in a fixed order: every thread strides the four lines, then two levels of partial sums
-    {
         float a[4][8];
 #pragma unroll
         for (int line = 0; line < 4; ++line)
@@ -285,7 +289,7 @@ __global__ __launch_bounds__(256) void cab_fold_kernel(const HatCabFoldDesc d) {
         }
         __syncthreads();
     }
-    if constexpr (DIRECT) {  // totals of the 8 channels: 32 interleaved sub-sums per channel, then a fixed-order sum
+    if (DIRECT && st == nullptr) {  // totals of the 8 channels: 32 interleaved sub-sums per channel, then a fixed-order sum
         const int c = tid & 7, sb = tid >> 3;
         float a[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};   // 8 loads in flight per thread
         for (int t = sb; t < d.tiles; t += 256) {
@@ -303,7 +307,9 @@ __global__ __launch_bounds__(256) void cab_fold_kernel(const HatCabFoldDesc d) {
         const int tap = tid >> 3, c = tid & 7;
         const int dy = tap / 3 - 1, dx = tap % 3 - 1;
         float tot = 0.f;
-        if constexpr (DIRECT) {
+        if (st != nullptr) {
+            tot = st[c];
+        } else if constexpr (DIRECT) {
             for (int p = 0; p < 32; ++p) tot += part[c][p];
         } else {
             for (int p = 0; p < 32; ++p) tot += d.tmp[((size_t)b * 32 + p) * d.ldcs + c];
@@ -315,7 +321,7 @@ __global__ __launch_bounds__(256) void cab_fold_kernel(const HatCabFoldDesc d) {
         if (cl >= 0) v -= bord[cl][c];
         if (rl >= 0 && cl >= 0) {
             const size_t pix = (size_t)(rl == 0 ? 0 : H - 1) * W + (cl == 2 ? 0 : W - 1);
-            v += to_f(c1[pix * d.ld1 + c]);
+            v += st != nullptr ? st[40 + (rl * 2 + (cl - 2)) * 8 + c] : to_f(c1[pix * d.ld1 + c]);
         }
         S[tap][c] = c < mid ? v : 0.f;
     }
@@ -507,13 +513,14 @@ extern "C" int hat_eca_scale(const float* colsum, int32_t tiles, int32_t ldc, in
 extern "C" int hat_cab_fold(const HatCabFoldDesc* dp, void* stream) {
     if (!dp) return HAT_EINVAL;
     const HatCabFoldDesc& d = *dp;
-    if (!d.c1 || !d.c1_colsum || !d.w2 || !d.b2 || !d.wk || !d.bias_in || !d.scale || !d.wf || !d.bias_out || !d.tmp) return HAT_EINVAL;
+    if (!d.w2 || !d.b2 || !d.wk || !d.bias_in || !d.scale || !d.wf || !d.bias_out) return HAT_EINVAL;
+    if (!d.stats && (!d.c1 || !d.c1_colsum || !d.tmp)) return HAT_EINVAL;
     if (d.B < 1 || d.H < 2 || d.W < 2 || d.C < 1 || d.C > 256 || d.mid < 1 || d.mid > 8 || d.ld1 != 8 || d.tiles < 1 || d.ldcs < 8 ||
         d.ldcs > 256 || d.k < 1 || (d.k & 1) == 0 || d.ld_scale < d.C)
         return HAT_EINVAL;
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     if (d.dtype != HAT_BF16 && d.dtype != HAT_F32) return HAT_EINVAL;
-    if (d.tiles <= 2048) {
+    if (d.tiles <= 2048 || d.stats) {
         if (d.dtype == HAT_BF16) HAT_LAUNCH((cab_fold_kernel<bf16_t, true>), dim3(d.B), dim3(256), 0, s, d);
         else HAT_LAUNCH((cab_fold_kernel<float, true>), dim3(d.B), dim3(256), 0, s, d);
         return hat_check_launch();
@@ -553,6 +560,77 @@ __global__ __launch_bounds__(256) void add_f32_kernel(const float* __restrict__ 
     for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long)gridDim.x * 256) ov[i] = av[i] + cv[i];
 }
 }  // namespace
+
+// ---------------------------------------------------------------------------------------------
+// hat_rect_sum: per-channel sums over a pixel rectangle of a channel-last map, deterministic (fixed reduction order):
+// every workgroup sums a contiguous share of the rectangle's pixels, the LAST one to finish adds the shares in order.
+// ---------------------------------------------------------------------------------------------
+namespace {
+template <typename T>
+__global__ __launch_bounds__(256) void rect_sum_kernel(const T* __restrict__ x, int ld, int C, int W, int r0, int c0, int rw, long npx,
+                                                       long bstride, float* __restrict__ out, int ldo, float* __restrict__ tmp,
+                                                       unsigned* __restrict__ counter) {
+    __shared__ float red[256 * 4];
+    __shared__ unsigned last;
+    const int tid = threadIdx.x, b = blockIdx.y, nwg = gridDim.x;
+    const int cpp = (C + 3) / 4;              // threads per pixel (4 channels each)
+    const int ppi = 256 / cpp;                // pixels per pass
+    const int slot = tid / cpp, cg = tid - slot * cpp;
+    const long share = (npx + nwg - 1) / nwg, p0 = (long)blockIdx.x * share, p1 = p0 + share < npx ? p0 + share : npx;
+    const T* xb = x + (size_t)b * bstride;
+    f32x4 a = {0.f, 0.f, 0.f, 0.f};
+    if (slot < ppi) {
+        for (long p = p0 + slot; p < p1; p += ppi) {
+            const long r = p / rw, c = p - r * rw;
+            const T* src = xb + ((size_t)(r0 + r) * W + (c0 + c)) * ld + 4 * cg;
+            a += Vec4<T>::load(src);       // (rows are padded to a multiple of 4 channels: pad channels are zero)
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) red[tid * 4 + k] = slot < ppi ? a[k] : 0.f;
+    __syncthreads();
+    float* mine = tmp + ((size_t)b * nwg + blockIdx.x) * 256;
+    if (tid < 4 * cpp) {                       // channel tid of this workgroup's share: the pixel slots in order
+        const int g2 = tid >> 2, k = tid & 3;
+        float s = 0.f;
+        for (int sl = 0; sl < ppi; ++sl) s += red[(sl * cpp + g2) * 4 + k];
+        mine[tid] = s;
+    }
+    __threadfence();
+    __syncthreads();
+    if (tid == 0) last = atomicAdd(counter + b, 1u) == (unsigned)(nwg - 1);
+    __syncthreads();
+    if (last) {
+        __threadfence();
+        if (tid < 4 * cpp) {
+            double s = 0.0;
+            for (int g2 = 0; g2 < nwg; ++g2) s += (double)__builtin_nontemporal_load(tmp + ((size_t)b * nwg + g2) * 256 + tid);
+            if (tid < ldo) out[(size_t)b * ldo + tid] = tid < C ? (float)s : 0.f;
+        }
+        if (tid == 0) counter[b] = 0u;         // self-resetting: the next launch on this stream finds it zero
+    }
+}
+}  // namespace
+
+extern "C" int hat_rect_sum(const void* x, int32_t dtype, int32_t ld, int32_t C, int32_t W, int32_t r0, int32_t r1, int32_t c0,
+                            int32_t c1, int64_t bstride, int32_t B, float* out, int32_t ldo, float* tmp, uint32_t* counter,
+                            void* stream) {
+    if (!x || !out || !tmp || !counter || B < 1 || C < 1 || C > 256 || ld < C || ld % 4 || W < 1 || r0 < 0 || r1 <= r0 || c0 < 0 ||
+        c1 <= c0 || c1 > W || ldo < 1 || ldo > 256)
+        return HAT_EINVAL;
+    const long npx = (long)(r1 - r0) * (c1 - c0);
+    const int nwg = (int)(npx >= 64 * 1024 ? 64 : (npx + 1023) / 1024);
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    if (dtype == HAT_BF16)
+        HAT_LAUNCH(rect_sum_kernel<bf16_t>, dim3(nwg, B), dim3(256), 0, s, reinterpret_cast<const bf16_t*>(x), ld, C, W, r0, c0, c1 - c0, npx,
+                   (long)bstride, out, ldo, tmp, counter);
+    else if (dtype == HAT_F32)
+        HAT_LAUNCH(rect_sum_kernel<float>, dim3(nwg, B), dim3(256), 0, s, reinterpret_cast<const float*>(x), ld, C, W, r0, c0, c1 - c0, npx,
+                   (long)bstride, out, ldo, tmp, counter);
+    else
+        return HAT_EINVAL;
+    return hat_check_launch();
+}
 
 extern "C" int hat_add_f32(const float* a, const float* c, float* out, int32_t B, int64_t n, int64_t c_bstride, void* stream) {
     if (!a || !c || !out || B < 1 || n < 4 || n % 4 || c_bstride < 0 || c_bstride % 4) return HAT_EINVAL;

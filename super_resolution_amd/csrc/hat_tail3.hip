@@ -24,6 +24,20 @@
 // partials and compact 16-channel copy) is the second generation's.
 #include "hat_common.h"
 
+// compile-time experiment switches (tools/ubench_tail3.hip builds the variants; the library builds the defaults)
+#ifndef T3_ISSUE_ALL
+#define T3_ISSUE_ALL 0      // 1: all three tiles' stage-0 loads up front (0: the third tile's after the first tile's MFMAs)
+#endif
+#ifndef T3_APF
+#define T3_APF 1            // fc1 A-fragment prefetch distance in k-steps (two fragments per step)
+#endif
+#ifndef T3_S0RD
+#define T3_S0RD 8           // stage 0: A-fragment read distance in MFMAs
+#endif
+#ifndef T3_DMA_LATE
+#define T3_DMA_LATE 0       // 1: the next chunk's fc1 copies are issued after the barrier that ends phase A instead of at the chunk top
+#endif
+
 namespace {
 
 typedef _Float16 h2 __attribute__((ext_vector_type(2)));
@@ -191,8 +205,11 @@ __global__ __launch_bounds__(256, 2) void tail3_kernel(const HatFfnDesc d, const
         };
         issue_tile(2);
         issue_tile(0);
+        if constexpr (T3_ISSUE_ALL) issue_tile(1);
         stamp(8);
-        asm volatile("s_waitcnt vmcnt(34)" ::: "memory");   // 53 operations issued: the 19 oldest (the copies) have landed
+        // 53 (70) operations issued: the 19 oldest (the copies) have landed
+        if constexpr (T3_ISSUE_ALL) asm volatile("s_waitcnt vmcnt(51)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(34)" ::: "memory");
         lds_barrier();     // ... and everybody's have
         stamp(9);
         typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
@@ -203,19 +220,21 @@ __global__ __launch_bounds__(256, 2) void tail3_kernel(const HatFfnDesc d, const
             f32x4 v[NT];
 #pragma unroll
             for (int nt = 0; nt < NT; ++nt) v[nt] = t == 2 ? accx[nt] : acc2[nt][t];
-            constexpr int RD = 3;
+            // (A fragment reads T3_S0RD MFMAs ahead of their use, the order pinned: left to the scheduler each read is sunk to
+            // just before its MFMA — one LDS latency per MFMA, 22 k cycles for the 216 of them in the first build)
+            constexpr int RD = T3_S0RD;
             u32x4 ar[RD];
 #pragma unroll
             for (int i = 0; i < RD; ++i) ar[i] = lds_rd16(lds0 + (unsigned)(i * 1024) + lane16);
 #pragma unroll
             for (int i = 0; i < NT * 8; ++i) {
                 const int nt = i >> 3, ks = i & 7;
-                const bf8 a = __builtin_bit_cast(bf8, ar[i % RD]);
+                v[nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf8, ar[i % RD]), bfr[t][ks], v[nt], 0, 0, 0);
                 if (i + RD < NT * 8) ar[i % RD] = lds_rd16(lds0 + (unsigned)((i + RD) * 1024) + lane16);
-                v[nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, bfr[t][ks], v[nt], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
             }
             __builtin_amdgcn_sched_barrier(0);
-            if (o == 0) issue_tile(1);   // (into the registers the halo tile's B fragments just left)
+            if (o == 0 && !T3_ISSUE_ALL) issue_tile(1);   // (into the registers the halo tile's B fragments just left)
             // LayerNorm2 WITHOUT its affine part (ops.pack_ffn3 folds gamma into the fc1 columns and W1.beta into the fc1
             // bias): fp32 statistics over the 4 lane groups of a pixel
             float s = 0.f;
@@ -286,7 +305,7 @@ __global__ __launch_bounds__(256, 2) void tail3_kernel(const HatFfnDesc d, const
         // weights: fc2 + depthwise taps of THIS chunk (needed after the next barrier), fc1 of the next chunk (needed after the
         // barrier that ends this one).  Their buffers' last readers passed the barrier that ended the previous chunk.
         dma_rest(chunk);
-        dma_fc1(min(chunk + 1, d.chunks - 1), (chunk + 1) & 1);
+        if constexpr (!T3_DMA_LATE) dma_fc1(min(chunk + 1, d.chunks - 1), (chunk + 1) & 1);
         // ================================ phase A: fc1 -> Us (fp16) ====================================
         {
             const unsigned w1b = lds0 + T3_W1_OFF + (unsigned)((chunk & 1) * T3_W1_BYTES) + lane16;
@@ -303,29 +322,30 @@ __global__ __launch_bounds__(256, 2) void tail3_kernel(const HatFfnDesc d, const
                     *(__attribute__((address_space(3))) u32x4*)(uintptr_t)(ust[t] + (unsigned)(p * 64)) = pk;
                 }
             };
-            bf8 acur[2], anxt[2];
-            acur[0] = __builtin_bit_cast(bf8, lds_rd16(w1b));
-            acur[1] = __builtin_bit_cast(bf8, lds_rd16(w1b + KS * 1024));
+            // A fragments of step s = (pair p, k-step ks): two per step, requested T3_APF steps ahead of their MFMAs
+            constexpr int APF = T3_APF, NSTEP = 2 * KS;
+            u32x4 ar[APF + 1][2];
+            auto rd_a = [&](int step) {
+                const int p1 = step / KS, k1 = step % KS;
+                ar[step % (APF + 1)][0] = lds_rd16(w1b + (unsigned)(((2 * p1) * KS + k1) * 1024));
+                ar[step % (APF + 1)][1] = lds_rd16(w1b + (unsigned)(((2 * p1 + 1) * KS + k1) * 1024));
+            };
+#pragma unroll
+            for (int i = 0; i < APF; ++i) rd_a(i);
 #pragma unroll
             for (int p = 0; p < 2; ++p) {
 #pragma unroll
                 for (int ks = 0; ks < KS; ++ks) {
                     const int step = p * KS + ks;
-                    if (step + 1 < 2 * KS) {   // next step's two A fragments: requested before this step's MFMAs
-                        const int p1 = (step + 1) / KS, k1 = (step + 1) % KS;
-                        anxt[0] = __builtin_bit_cast(bf8, lds_rd16(w1b + (unsigned)(((2 * p1) * KS + k1) * 1024)));
-                        anxt[1] = __builtin_bit_cast(bf8, lds_rd16(w1b + (unsigned)(((2 * p1 + 1) * KS + k1) * 1024)));
-                    }
+                    if (step + APF < NSTEP) rd_a(step + APF);
 #pragma unroll
                     for (int ii = 0; ii < 2; ++ii)
 #pragma unroll
                         for (int t = 0; t < 3; ++t) {
                             const f32x4 c0 = ks == 0 ? f32x4{0.f, 0.f, 0.f, 0.f} : acc[p][ii][t];
-                            acc[p][ii][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(acur[ii], mb[t][ks], c0, 0, 0, 0);
+                            acc[p][ii][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf8, ar[step % (APF + 1)][ii]), mb[t][ks], c0, 0, 0, 0);
                         }
                     __builtin_amdgcn_sched_barrier(0);
-                    acur[0] = anxt[0];
-                    acur[1] = anxt[1];
                 }
                 // the conversion + store of pair 0 is issued after the MFMAs of pair 1 were: their results are long complete
                 if (p == 1) store_u(0);
@@ -333,9 +353,12 @@ __global__ __launch_bounds__(256, 2) void tail3_kernel(const HatFfnDesc d, const
             store_u(1);
         }
         stamp(2);
-        asm volatile("s_waitcnt vmcnt(5)" ::: "memory");   // all but the 5 youngest copies (next chunk's fc1) have landed
+        // all but the 5 youngest copies (next chunk's fc1) have landed
+        if constexpr (T3_DMA_LATE) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
         lds_barrier();     // Us, fc2 fragments and depthwise taps complete
         stamp(3);
+        if constexpr (T3_DMA_LATE) dma_fc1(min(chunk + 1, d.chunks - 1), (chunk + 1) & 1);
 
         // ====================== phase B: depthwise 3x3 in packed fp16 (this wave's two rows) ======================
         h2 da[2][4], dg[2][4];   // [tile row][dword]: a-units / gate-units 8g..8g+7, two per dword

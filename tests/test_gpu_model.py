@@ -248,7 +248,9 @@ def test_unfused_tail_switches_keep_the_13x13_conv_on_fresh_rows(monkeypatch, sw
     """Round-2 advisor finding: with the fused tail off (HAT_NO_HAB_TAIL=1) or the first-generation FFN kernel (HAT_FFN_V1=1)
     and the group conv's LayerNorm epilogue ON, hat_ffn / hat_ffn2 emit the next LayerNorm rows but no compact 16-channel
     copy — the engine must then not hand the group conv's stale copy to the next block's 13x13 conv.  Held against the
-    reference golden at the bf16 bar and against the default sequence (two bf16 runs: >= 44 dB)."""
+    reference golden at the bf16 bar and against the default sequence (two bf16 evaluations that round at different places —
+    hat_ffn keeps the hidden tensor in bf16, the default tail in fp16 with LayerNorm2's affine folded into fc1: measured 43.8 to
+    47 dB; the stale-copy bug this test is for gave < 30 dB)."""
     dev = _dev()
     g = golden("summary_HAT-S_x4_64.npz")
     x = synth.synth_input(X_SEED, tuple(int(v) for v in g["x_shape"])).to(dev)
@@ -257,7 +259,7 @@ def test_unfused_tail_switches_keep_the_13x13_conv_on_fresh_rows(monkeypatch, sw
     y_sw = build_net("HAT-S_x4", "bf16", dev)(x).float().cpu()
     torch.cuda.synchronize()
     assert torch.isfinite(y_sw).all()
-    assert O.psnr_float(y_sw, y_def) >= 44.0, O.psnr_float(y_sw, y_def)
+    assert O.psnr_float(y_sw, y_def) >= 42.0, O.psnr_float(y_sw, y_def)
     for k in ("tl", "br", "ce"):
         a, b, c = (int(v) for v in g["pos_" + k])
         assert_close(y_sw[..., a:a + c, b:b + c], torch.as_tensor(g["crop_" + k]), "bf16", f"HAT-S x4 64x64 with {switch}=1, crop {k}")
