@@ -112,7 +112,9 @@ def main():
     ap.add_argument("--height", type=int, default=720)
     ap.add_argument("--width", type=int, default=1280)
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32"])
-    ap.add_argument("--mode", default="tiles", choices=["tiles", "frames"], help="N>1: one frame cut in tiles, or one frame per rank")
+    ap.add_argument("--mode", default="tiles", choices=["tiles", "frames", "shard"],
+                    help="N>1: one frame cut in independent tiles (reference tile semantics), one frame per rank, or one frame "
+                         "sharded EXACTLY into row bands that exchange halo rows and pool sums (SURVEY §8 f4)")
     ap.add_argument("--tile-pad", type=int, default=32)
     ap.add_argument("--cpu-crop", type=int, default=256, help="side of the crop timed on the CPU (0 disables the baseline)")
     ap.add_argument("--no-kernel-profile", action="store_true")
@@ -177,6 +179,13 @@ def main():
 
         def step():
             return net(x)
+    elif args.mode == "shard":
+        workload = (f"{args.model} x{s}, one 3x{H}x{W} LR frame sharded exactly into {world} row bands (halo rows by send/recv "
+                    f"between neighbours, pool sums by all-reduce), one band per GPU + all-gather of output rows")
+        scaling = "strong"
+
+        def step():
+            return net.forward_band_parallel(x)
     else:
         tiles = tp.balanced_tiles(Hp, Wp, world, ws, args.tile_pad)
         workload = (f"{args.model} x{s}, one 3x{H}x{W} LR frame cut into {world} window-aligned tiles "
@@ -215,7 +224,7 @@ def main():
         reps = 2
         for _ in range(reps):
             with ops.profile() as rec:
-                if world == 1 or args.mode == "frames":
+                if world == 1 or args.mode in ("frames", "shard"):   # (shard: the kernels of a full frame; a band's are a slice of them)
                     net(x)
                 else:
                     tp.run_tile(x, net, tiles[tp.assign(tiles, world)[0][0]], s)
@@ -282,7 +291,7 @@ def main():
             "value": round(value, 3), "unit": "MP/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(ms_per_step, 3), "higher_is_better": True, "scaling": scaling, "vs_baseline": None,
             "dtype": args.dtype, "data": "synthetic (uniform[0,1) LR frame, seeded random weights; no checkpoints exist for this fork)",
-            "config": {"workload": workload, "lr_size": [H, W], "upscale": s, "parallelism": f"tile{world}" if scaling == "strong" else f"dp{world}"},
+            "config": {"workload": workload, "lr_size": [H, W], "upscale": s, "parallelism": (f"band{world}" if args.mode == "shard" else f"tile{world}") if scaling == "strong" else f"dp{world}"},
             "path": {"algorithmic_tflop_per_frame": round(fl_frame / 1e12, 3), "achieved_tflops": round(path_tflops, 2),
                      "frac_of_mfma_peak": round(path_tflops / (MFMA_PEAK_TFLOPS[args.dtype] * world), 4)},
             "roofline": roofline,

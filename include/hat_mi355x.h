@@ -466,7 +466,7 @@ void hat_plan_free(hat_plan* plan);
 
 /*
  * Per-channel sums of a channel-last map over the pixel rectangle rows [r0, r1) x columns [c0, c1):
- *     out[b][ch] = sum x[b][(r*W + c)*ld + ch],  ch < C (out[b][C..ldo) = 0),  x: T = bf16 / fp32, ld % 4 == 0 with zero pad channels
+ *     out[b*ldo + ch] = sum x[b][(r*W + c)*ld + ch],  ch < C,  x: T = bf16 / fp32, ld % 4 == 0 with zero pad channels
  * — the global average pools of the path (ECA, hat_arch.py:73; ESC dynamic kernel, esc_arch.py:96,121) when a frame is sharded
  * into row bands and every band contributes the sums of the rows it OWNS; the bands' vectors are then added
  * (hat_add_f32 on one GPU, an RCCL all-reduce across GPUs) and fed to hat_esc_weights / hat_eca_scale as ONE block, to

@@ -344,6 +344,31 @@ class HAT(nn.Module):
                 return self._forward_graph(x)
             return self.engine(x.device).forward(x).to(x.dtype)
 
+    # ---- exact full-frame sharding into row bands (no counterpart in the reference, whose tile loop
+    # hat_model.py:40-108 gives a DIFFERENT result than the full frame: SURVEY F6) ----
+    def _check_band_input(self, x):
+        if self.training:
+            raise RuntimeError("this HAT implements the inference forward pass only: call .eval() first")
+        if not x.is_cuda:
+            raise RuntimeError("HAT.forward needs a GPU tensor: the MI355X HIP path is the only path (no CPU fallback)")
+
+    def forward_bands(self, x, n_bands: int):
+        """`forward(x)` computed as n_bands row bands on this GPU that exchange halo rows and pool sums: equal to the
+        unsharded forward up to the summation order of the two global pools (band_parallel.forward_bands_local)."""
+        from .. import band_parallel
+        self._check_band_input(x)
+        with torch.no_grad():
+            return band_parallel.forward_bands_local(self.engine(x.device), x, n_bands).to(x.dtype)
+
+    def forward_band_parallel(self, x, group=None):
+        """`forward(x)` with one row band per rank of `group` (torch.distributed; RCCL send / recv of halo rows between
+        neighbours, one small all-reduce per pool, one all-gather of the output rows): every rank passes the same x and
+        receives the full output frame (band_parallel.forward_band_distributed)."""
+        from .. import band_parallel
+        self._check_band_input(x)
+        with torch.no_grad():
+            return band_parallel.forward_band_distributed(self.engine(x.device), x, group).to(x.dtype)
+
     def _forward_graph(self, x):
         """Replay the whole forward (about 290 launches on two streams) as one HIP graph: captured once per input
         shape after two eager warm-up passes, input copied into the graph's static buffer, output copied out of it.

@@ -101,7 +101,7 @@ __global__ __launch_bounds__(256, KS > 2 ? 2 : 3) void cab_squeeze_kernel(const 
 #pragma unroll
                 for (int i = 0; i < 4; ++i) v[i] = gelu_erf_fast(v[i]);
                 Vec4<bf16_t>::store(ob + ((size_t)y * W + x0 + c16) * 8 + 4 * g, v);
-                csum += v;
+                csum += as_stored<bf16_t>(v);
             }
         }
         S2 = f32x4{0.f, 0.f, 0.f, 0.f};

@@ -116,6 +116,17 @@ template <> struct Vec4<bf16_t> {
     }
 };
 
+// The value a stored T holds: what a pool over a stored map must add (the ESC pool, esc_arch.py:96,121, is a mean of the very
+// tensor the 13x13 conv then reads — here the T-rounded LayerNorm output; pooling the unrounded fp32 values instead makes the
+// pool depend on WHO computes it: a band-sharded frame pools the stored rows).
+template <typename T> __device__ __forceinline__ f32x4 as_stored(f32x4 v) {
+    if constexpr (sizeof(T) == 2) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v[r] = (float)(bf16_t)v[r];
+    }
+    return v;
+}
+
 // Two adjacent n-tiles' accumulators of one pixel -> ONE 16-byte bf16 store per lane.  In the MFMA D layout lane group g
 // holds channels 4g..4g+3 of every n-tile, so a plain store is 8 bytes per lane and 32 contiguous bytes per pixel.
 // v_permlane16_swap exchanges the odd 16-lane rows of its first operand with the even rows of its second: afterwards an

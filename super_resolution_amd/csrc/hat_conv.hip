@@ -329,7 +329,7 @@ __global__ __launch_bounds__(WAVES * 64) void conv_kernel(const HatConvDesc d) {
                                         v[r] * d.out_scale + d.mean[(n + r) & 3];
                         }
                     }
-                    if (want_cs && valid) csum += v;
+                    if (want_cs && valid) csum += d.out_mode == HAT_O_NHWC_T ? as_stored<T>(v) : v;   // (the pool of the STORED map)
                 }
                 if (want_cs) {
 #pragma unroll
@@ -376,7 +376,7 @@ __global__ __launch_bounds__(WAVES * 64) void conv_kernel(const HatConvDesc d) {
                         Vec4<T>::store(lo + n, o);
                         if (nt == 0) {
                             if (d.n16_out != nullptr) Vec4<T>::store(reinterpret_cast<T*>(d.n16_out) + pix * 16 + n, o);
-                            if (n < d.gap_c) gapv += o;
+                            if (n < d.gap_c) gapv += as_stored<T>(o);
                         }
                     }
                 }

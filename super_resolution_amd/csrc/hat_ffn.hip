@@ -473,7 +473,7 @@ __global__ __launch_bounds__(WAVES * 64, MINW) void ffn_kernel(const HatFfnDesc 
 #pragma unroll
                     for (int r = 0; r < 4; ++r) o[r] = (acc2[nt][pt][r] - mean) * rstd * g1v[nt][r] + b1v[nt][r];
                     Vec4<T>::store(nout + n, o);
-                    if (nt == 0 && n < d.gap_c) gapv += o;
+                    if (nt == 0 && n < d.gap_c) gapv += as_stored<T>(o);
                 }
             }
         }

@@ -443,7 +443,7 @@ __global__ __launch_bounds__(WAVES * 64, MINW) void tap3_kernel(const HatConvDes
 #pragma unroll
                         for (int r = 0; r < 4; ++r) v[r] = v[r] >= 0.f ? v[r] : 0.01f * v[r];
                     }
-                    csum[nt] += v;
+                    csum[nt] += d.out_mode == HAT_O_NHWC_T ? as_stored<T>(v) : v;   // (the pool of the STORED map)
                     if (d.out_mode == HAT_O_NHWC_T) Vec4<T>::store(reinterpret_cast<T*>(d.out) + pix * d.ldo + n, v);
                     else *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(d.out) + pix * d.ldo + n) = v;
                 }

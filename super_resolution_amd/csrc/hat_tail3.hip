@@ -484,7 +484,7 @@ __global__ __launch_bounds__(256, 2) void tail3_kernel(const HatFfnDesc d, const
                 for (int r = 0; r < 4; ++r) o[r] = (acc2[nt][pt][r] - mean) * rstd * g1v[nt][r] + bt1v[nt][r];
                 if (valid) {
                     Vec4<bf16_t>::store(nout + nt * 16 + 4 * g, o);
-                    if (nt == 0 && 4 * g < d.gap_c) gapv += o;
+                    if (nt == 0 && 4 * g < d.gap_c) gapv += as_stored<bf16_t>(o);
                     if (nt == 0 && d.n16_out != nullptr)   // compact copy of channels 0..15 for the next block's ESC conv
                         Vec4<bf16_t>::store(reinterpret_cast<bf16_t*>(d.n16_out) + ((size_t)b * H * W + pix) * 16 + 4 * g, o);
                 }

@@ -249,8 +249,9 @@ class HATEngine:
         return ops.pack_conv_weight(w, sd[key + ".bias"], self.dtype, self.dev, out_perm=perm)
 
     # ------------------------------------------------------------------------------------------
-    def _workspace(self, B, H, W):
-        key = (B, H, W)
+    def _workspace(self, B, H, W, tag=None):
+        """tag: a row band of a sharded frame gets a workspace of its own (two bands of one shape must not share buffers)."""
+        key = (B, H, W) if tag is None else (B, H, W, tag)
         ws = self._ws_cache.get(key)
         if ws is not None:
             self._ws_cache.move_to_end(key)
@@ -296,6 +297,11 @@ class HATEngine:
             w["colsum1"] = z(B, w["tiles1"], cab0.npad, dtype=f)
             w["wf"] = z(B, hab0["esc"].aggr.nt * 3 * 512)
             w["bias_b"] = z(B, hab0["esc"].aggr.npad, dtype=f)
+        if tag is not None:   # pooled sums of this band's own rows (local) and of the whole frame (global): SURVEY §8 f4
+            w["gstat_l"], w["gstat_g"] = z(B, yw, dtype=f), z(B, yw, dtype=f)
+            w["cstat_l"], w["cstat_g"] = z(B, 72, dtype=f), z(B, 72, dtype=f)
+            w["estat_l"], w["estat_g"] = z(B, 256, dtype=f), z(B, 256, dtype=f)
+            w["rs_tmp"], w["rs_cnt"] = z(B, 64, 256, dtype=f), torch.zeros(B, dtype=torch.int32, device=dev)
         h, wd = H, W
         w["ups"] = []
         for _, r in self.ups:
@@ -311,9 +317,10 @@ class HATEngine:
         return w
 
     # ------------------------------------------------------------------------------------------
-    def _esc_w(self, esc: _ESC, w, B, H, W, nblk):
-        """The per-sample 13x13 weights of the ESC conv (static filter + dynamic depthwise kernel) -> w['weff']."""
-        ops.esc_weights(w["gap"], nblk, H * W, esc.w1, esc.b1, esc.w2, esc.b2, esc.plk, w["weff"], B=B,
+    def _esc_w(self, esc: _ESC, w, B, H, W, nblk, gap=None):
+        """The per-sample 13x13 weights of the ESC conv (static filter + dynamic depthwise kernel) -> w['weff'].
+        gap: one block of frame-wide sums over H * W pixels (band-sharded frames) instead of w['gap']'s nblk partial blocks."""
+        ops.esc_weights(w["gap"] if gap is None else gap, nblk, H * W, esc.w1, esc.b1, esc.w2, esc.b2, esc.plk, w["weff"], B=B,
                         pdim=esc.pdim, ksize=esc.ksize, kpad=esc.kpad, dtype=self.dtype)
 
     def _esc_conv(self, esc: _ESC, w, n, B, H, W, n16=None):
@@ -355,6 +362,20 @@ class HATEngine:
             return self._forward(x, only_ocab=(t.to(self.dev, torch.float32).contiguous(), group))
 
     def _forward(self, x: torch.Tensor, only_ocab=None) -> torch.Tensor:
+        gen = self._forward_gen(x, only_ocab=only_ocab)
+        try:
+            req = next(gen)
+        except StopIteration as done:
+            return done.value
+        raise RuntimeError(f"the unsharded forward must not reach an exchange point (got {req[0]!r})")
+
+    def _forward_gen(self, x: torch.Tensor, only_ocab=None, band=None):
+        """The forward as a generator.  Unsharded (band=None) it never yields and returns the output.  For one ROW BAND of a
+        sharded frame (band: tile_parallel.Band, x = the band's rows + ghost rows of the LR frame) it yields at
+        every point where bands must exchange: ("halo", [(tensor, depth) ...]) — refresh `depth` ghost rows above and below
+        from the neighbours that own them — and ("reduce", local, glob, n) — glob[:, :n] = sum over bands of local[:, :n] (the
+        global average pools of ECA, hat_arch.py:69-73, and of the ESC dynamic kernel, esc_arch.py:96,121) — and returns the
+        band's output rows (ghost rows included; the driver keeps the owned ones)."""
         if x.dim() != 4 or x.shape[1] != self.cfg["in_chans"]:
             raise RuntimeError(f"expected (B,{self.cfg['in_chans']},H,W), got {tuple(x.shape)}")
         B, _, H, W = x.shape
@@ -364,7 +385,17 @@ class HATEngine:
         x = x.to(torch.float32).contiguous()
         cfg, dt, C = self.cfg, self.dtype, self.C
         N, ldc = H * W, _r8(C)
-        w = dict(self._workspace(B, H, W))   # (a shallow copy: the forward swaps the two LayerNorm-output buffers locally)
+        bd = band
+        w = dict(self._workspace(B, H, W, tag=(None if bd is None else ("band", bd.idx, bd.n))))   # (a shallow copy: the forward swaps the two LayerNorm-output buffers locally)
+        if bd is not None:
+            if (self.hatx or self.identity or self.ape is not None or self.pe_norm is None or self.conv_after_body is None
+                    or any("esc" in L["ocab"] for L in self.layers) or (bd.e1 - bd.e0) != H):
+                raise NotImplementedError("band-sharded forward: plain HAT with resi_connection='1conv', patch_norm, no ape, no OCAB-ESC")
+            lo, own, npix_full = bd.lo, bd.own, bd.Hfull * W
+
+            def pooled(src, ld, C_, dst, off=0, r0=None, r1=None, c0=0, c1=None):
+                ops.rect_sum(src, dst, w["rs_tmp"], w["rs_cnt"], B=B, W=W, ld=ld, C_=C_, r0=(lo if r0 is None else r0),
+                             r1=(lo + own if r1 is None else r1), c0=c0, c1=c1, out_off=off)
         s = self.scale
         y = torch.empty(B, cfg["in_chans"], H * s, W * s, dtype=torch.float32, device=self.dev)
         mean = RGB_MEAN if cfg["in_chans"] == 3 else (0.0,) * 4
@@ -384,6 +415,8 @@ class HATEngine:
             (same values as the conv's own staging conversion; 650 B/px less traffic per group)."""
             oc = L["ocab"]
             esc = oc.get("esc")  # OCAB                                                    :326-393
+            if bd is not None:   # key / value windows reach (wse - ws) / 2 rows into the neighbours' bands             :359-360
+                yield ("halo", [((w["n"] if have_n else t), (self.wse - ws + 1) // 2)])
             if not have_n:
                 ln(t, w["n"], oc["n1"], gap_c=(esc.pdim if esc else 0))
                 nblk = LNB
@@ -397,7 +430,8 @@ class HATEngine:
                 ops.ocab_qkv(oc["qkvf"], w["n"], w["qkv"], B=B, H=H, W=W, ldx=ldc, ldo=432, dtype=dt)
                 qbuf, kvbuf, ldq, ldkv = w["qkv"], w["qkv"].view(-1)[144:], 432, 432
             else:
-                s0, s1 = torch.cuda.current_stream(self.dev), self._side_stream()   # q and kv projections are independent
+                s0 = torch.cuda.current_stream(self.dev)   # q and kv projections are independent
+                s1 = s0 if bd is not None else self._side_stream()
                 s1.wait_stream(s0)
                 with torch.cuda.stream(s1):
                     self._run_lin(oc["q"], w["n"], w["q"], **geo, ldx=ldc, ldo=ldc)
@@ -438,7 +472,7 @@ class HATEngine:
         if only_ocab is not None:   # test hook: one OCAB on a given residual stream (block-level parity against reference goldens)
             t_in, gidx = only_ocab
             w["tB"].copy_(t_in.reshape(B, N, C))
-            return run_ocab(self.layers[gidx], w["tB"], False, ops.layernorm_blocks()).clone()
+            return (yield from run_ocab(self.layers[gidx], w["tB"], False, ops.layernorm_blocks())).clone()
         # (x - mean) * img_range ; conv_first                                           :849-853
         ops.conv(self.conv_first, x, w["f0"], **geo, ldx=0, ldo=C, x_mode=X_NCHW_F32_MEAN, out_mode=O_NHWC_F32,
                  in_scale=r, mean=mean)
@@ -464,9 +498,25 @@ class HATEngine:
             oc = L["ocab"]
             for i, hb in enumerate(L["habs"]):  # HAB                                     :217-238
                 esc = hb["esc"]
+                if bd is not None and not have_n:
+                    yield ("halo", [(t, 7)])          # (LayerNorm1 is recomputed on the ghost rows from the refreshed stream)
                 if not have_n:
                     ln(t, w["n"], hb["n1"], gap_c=esc.pdim)
                     nblk, have_n16 = LNB, False
+                elif bd is not None:
+                    # what this block reads beyond the band's own rows: t one row (depthwise 3x3 of the FFN), LayerNorm1's
+                    # output three rows (the two CAB convs under it) and its first pdim channels ksize / 2 + 1 = seven rows
+                    # (13x13 conv under the FFN's halo row)
+                    er = esc.ksize // 2 + 1
+                    yield ("halo", [(t, 1)] + ([(w["n"], 3), (w["n16"], er)] if have_n16 else [(w["n"], max(3, er))]))
+                gapb = None
+                if bd is not None:   # the ESC pool (esc_arch.py:96,121) over the whole FRAME: this band's share, then the sum
+                    if have_n16:
+                        pooled(w["n16"], 16, esc.pdim, w["gstat_l"])
+                    else:
+                        pooled(w["n"], ldc, esc.pdim, w["gstat_l"])
+                    yield ("reduce", w["gstat_l"], w["gstat_g"], esc.pdim)
+                    gapb = w["gstat_g"]
                 mid = hb["cab0"].nout
                 if "fold" in hb:
                     # c2 = conv3x3(c1) never exists: its ECA pooling follows from the sums of c1 (hat_cab_fold) and the
@@ -474,7 +524,8 @@ class HATEngine:
                     # The two tiny per-sample kernels (one workgroup each, latency-bound) run on a side stream next to the
                     # convs they do not depend on: esc_weights beside the CAB squeeze conv, cab_fold beside the 13x13 conv.
                     fo = hb["fold"]
-                    s0, s1 = torch.cuda.current_stream(self.dev), self._side_stream()
+                    s0 = torch.cuda.current_stream(self.dev)
+                    s1 = s0 if bd is not None else self._side_stream()
                     # The critical chain — ESC weight kernel -> 13x13 conv -> tail — stays on ONE stream: every hop between
                     # streams costs an event wait of ~12 us on this runtime (kernel trace: 2 hops per block = 0.9 ms per
                     # frame when the 13x13 conv sat on the side stream).  The CAB squeeze conv and its fold are shorter and
@@ -484,10 +535,33 @@ class HATEngine:
                             ops.cab_squeeze(w["n"], fo["sq"][0], fo["sq"][1], w["c1"], w["colsum1"], B=B, H=H, W=W, C_=C, ldx=ldc, dtype=dt)
                         else:
                             ops.conv(hb["cab0"], w["n"], w["c1"], **geo, ldx=ldc, ldo=8, act=ACT_GELU, n_store=8, colsum=w["colsum1"])
-                        ops.cab_fold(w["c1"], w["colsum1"], w["tiles1"], hb["cab0"].npad, fo["w2"], fo["b2"], hb["eca_w"],
-                                     hb["eca_w"].numel(), fo["ba"], float(cfg["conv_scale"]), w["scale"], w["wf"], w["bias_b"],
-                                     w["eca_tmp"], B=B, H=H, W=W, C_=C, mid=mid, dtype=dt)
-                    if os.environ.get("HAT_ESC_SIDE") == "1":
+                        if bd is None:
+                            ops.cab_fold(w["c1"], w["colsum1"], w["tiles1"], hb["cab0"].npad, fo["w2"], fo["b2"], hb["eca_w"],
+                                         hb["eca_w"].numel(), fo["ba"], float(cfg["conv_scale"]), w["scale"], w["wf"], w["bias_b"],
+                                         w["eca_tmp"], B=B, H=H, W=W, C_=C, mid=mid, dtype=dt)
+                    if bd is not None:
+                        # band-sharded: the sums hat_cab_fold takes from c1 (hat_arch.py:73 via the linearity of the expand conv)
+                        # are this band's share of [total | first row | last row | first column | last column | 4 corners]
+                        squeeze_chain()
+                        st = w["cstat_l"]
+                        pooled(w["c1"], 8, 8, st, 0)
+                        pooled(w["c1"], 8, 8, st, 24, c0=0, c1=1)
+                        pooled(w["c1"], 8, 8, st, 32, c0=W - 1, c1=W)
+                        if bd.r0 == 0:
+                            pooled(w["c1"], 8, 8, st, 8, r0=lo, r1=lo + 1)
+                            pooled(w["c1"], 8, 8, st, 40, r0=lo, r1=lo + 1, c0=0, c1=1)
+                            pooled(w["c1"], 8, 8, st, 48, r0=lo, r1=lo + 1, c0=W - 1, c1=W)
+                        if bd.r1 == bd.Hfull:
+                            pooled(w["c1"], 8, 8, st, 16, r0=lo + own - 1, r1=lo + own)
+                            pooled(w["c1"], 8, 8, st, 56, r0=lo + own - 1, r1=lo + own, c0=0, c1=1)
+                            pooled(w["c1"], 8, 8, st, 64, r0=lo + own - 1, r1=lo + own, c0=W - 1, c1=W)
+                        yield ("reduce", st, w["cstat_g"], 72)
+                        ops.cab_fold(None, None, 1, hb["cab0"].npad, fo["w2"], fo["b2"], hb["eca_w"], hb["eca_w"].numel(), fo["ba"],
+                                     float(cfg["conv_scale"]), w["scale"], w["wf"], w["bias_b"], None, B=B, H=bd.Hfull, W=W, C_=C,
+                                     mid=mid, dtype=dt, stats=w["cstat_g"])
+                        self._esc_w(esc, w, B, bd.Hfull, W, 1, gap=gapb)
+                        self._esc_conv(esc, w, w["n"], B, H, W, n16=(w["n16"] if have_n16 else None))
+                    elif os.environ.get("HAT_ESC_SIDE") == "1":
                         self._esc_w(esc, w, B, H, W, nblk)
                         s1.wait_stream(s0)                              # n and the 13x13 weights are ready
                         with torch.cuda.stream(s1):                     # chain 2: 13x13 conv
@@ -522,9 +596,21 @@ class HATEngine:
                     c3(hb["cab0"], w["n"], w["c1"], **geo, ldx=ldc, ldo=_r8(mid), act=ACT_GELU, n_store=_r4(mid))
                     c3 = ops.conv3x3_small if hb["cab2"].frag else ops.conv
                     c3(hb["cab2"], w["c1"], w["c2"], **geo, ldx=_r8(mid), ldo=ldc, colsum=w["colsum"])
-                    ops.eca_scale(w["colsum"], w["tiles"], hb["cab2"].npad, N, hb["eca_w"], hb["eca_w"].numel(),
-                                  float(cfg["conv_scale"]), w["eca_tmp"], w["scale"], B=B, C_=C)
-                    self._esc_lk(esc, w, w["n"], B, H, W, nblk)
+                    if bd is None:
+                        ops.eca_scale(w["colsum"], w["tiles"], hb["cab2"].npad, N, hb["eca_w"], hb["eca_w"].numel(),
+                                      float(cfg["conv_scale"]), w["eca_tmp"], w["scale"], B=B, C_=C)
+                        self._esc_lk(esc, w, w["n"], B, H, W, nblk)
+                    else:   # ECA pool of c2 (hat_arch.py:73) over the whole frame: this band's rows, then the sum over the bands
+                        # (rows of npad floats, like the per-tile column sums: hat_eca_scale writes `scale` with that stride and
+                        # the aggregation reads it so)
+                        npd = hb["cab2"].npad
+                        el, eg = (w[k].view(-1)[:B * npd].view(B, npd) for k in ("estat_l", "estat_g"))
+                        pooled(w["c2"], ldc, C, el)
+                        yield ("reduce", el, eg, _r4(C))
+                        ops.eca_scale(eg, 1, npd, npix_full, hb["eca_w"], hb["eca_w"].numel(),
+                                      float(cfg["conv_scale"]), w["eca_tmp"], w["scale"], B=B, C_=C)
+                        self._esc_w(esc, w, B, bd.Hfull, W, 1, gap=gapb)
+                        self._esc_conv(esc, w, w["n"], B, H, W)
                     # t = t + aggr(cat(y16, n[pdim:])) + conv_scale * eca * c2                :236
                     # hat_linear can emit LayerNorm2 of its result as hat_ffn's m_in, turning the FFN's stage 0 into a copy.
                     # Measured at 720p HAT-S: FFN -0.034 ms, aggr +0.070 ms per block (320 more bytes per pixel to write,
@@ -563,7 +649,9 @@ class HATEngine:
                     t, have_n, have_n16 = tB, False, False
             to_conv = (L["conv"] is not None and dt == ops.HAT_BF16 and ldc == C and L["ocab"]["mlp2"].frag
                        and not os.environ.get("HAT_NO_BF16_CONV_IN"))
-            tout = run_ocab(L, t, have_n, nblk, as_conv_input=to_conv)
+            tout = yield from run_ocab(L, t, have_n, nblk, as_conv_input=to_conv)
+            if bd is not None and L["conv"] is not None:   # the group's 3x3 conv reads one row beyond the band's own
+                yield ("halo", [(tout, 1)])
             # RHAG tail: conv3x3 + group residual, written over the group input             :556
             if L["conv"] is None:  # resi_connection == 'identity': group(x) + x                 :545-546
                 ops.add_f32(tout, tA, tA, B=B, n=N * C)
@@ -589,6 +677,11 @@ class HATEngine:
             ops.add_f32(tB, w["f0"], tB, B=B, n=N * C)
             ops.conv(self.conv_before_up, tB, w["fb"], **geo, ldx=C, ldo=64, x_mode=X_NHWC_F32, act=ACT_LRELU)
         else:
+            if bd is not None:
+                # conv_after_body, conv_before_upsample, the Upsample convs and conv_last are five 3x3 convs, the last two at
+                # 2x / 4x resolution: their receptive field is < 4 LR rows.  ONE refresh of 8 rows here, then the band computes
+                # its ghost rows redundantly (f0 = conv_first(x) is exact there: the band's x carries the ghost rows).
+                yield ("halo", [((w["n"] if grp_n else tA), 8)])
             if not grp_n:
                 ln(tA, w["n"], self.norm)
             ops.conv(self.conv_after_body, w["n"], w["c2"], **geo, ldx=ldc, ldo=ldc, r1=w["f0"], ldr1=C)

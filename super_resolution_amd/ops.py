@@ -198,6 +198,19 @@ def add_f32(a: torch.Tensor, c: torch.Tensor, out: torch.Tensor, *, B: int, n: i
     _timed("add_f32_kernel", 0.0, lambda: _lib.check(lib.hat_add_f32(_ptr(a), _ptr(c), _ptr(out), B, n, cb, _stream()), "hat_add_f32"))
 
 
+def rect_sum(x: torch.Tensor, out: torch.Tensor, tmp: torch.Tensor, counter: torch.Tensor, *, B: int, W: int, ld: int, C_: int, r0: int,
+             r1: int, c0: int = 0, c1: Optional[int] = None, out_off: int = 0, dtype: Optional[int] = None):
+    """out[b][out_off : out_off + C_] = per-channel sums of x (B, rows*W, ld) over rows [r0, r1) x columns [c0, c1) (hat_rect_sum):
+    the pooled sums a row band of a sharded frame contributes."""
+    lib = _lib.load()
+    dt = dtype if dtype is not None else (HAT_BF16 if x.dtype == torch.bfloat16 else HAT_F32)
+    o = out.view(B, -1)
+    bstride = x.numel() // B
+    _timed("rect_sum_kernel", 0.0, lambda: _lib.check(
+        lib.hat_rect_sum(_ptr(x), dt, ld, C_, W, r0, r1, c0, (W if c1 is None else c1), bstride, B, o.data_ptr() + 4 * out_off, o.shape[1],
+                         _ptr(tmp), _ptr(counter), _stream()), "hat_rect_sum"))
+
+
 def esc_weights(gap: torch.Tensor, nblk: int, npix: int, w1, b1, w2, b2, plk_packed, w_out, *, B: int, pdim: int,
                 ksize: int, kpad: int, dtype: int):
     lib = _lib.load()
@@ -768,9 +781,12 @@ def aggr_cab_supported(C_: int, mid: int, dtype: int) -> bool:
 
 
 def cab_fold(c1, c1_colsum, tiles: int, ldcs: int, w2, b2, wk, k: int, bias_in, conv_scale: float, scale, wf, bias_out, tmp, *,
-             B: int, H: int, W: int, C_: int, mid: int, dtype: int):
+             B: int, H: int, W: int, C_: int, mid: int, dtype: int, stats=None):
+    """stats: (B, >= 72) fp32 = the frame-wide sums of c1 ([total 8 | first row | last row | first column | last column | four
+    corner pixels]); H, W are then the FULL frame's and c1 / c1_colsum are not read (band-sharded frames)."""
     lib = _lib.load()
     d = HatCabFoldDesc()
+    d.stats = _ptr(stats)
     d.c1, d.c1_colsum, d.w2, d.b2, d.wk, d.bias_in = _ptr(c1), _ptr(c1_colsum), _ptr(w2), _ptr(b2), _ptr(wk), _ptr(bias_in)
     d.scale, d.wf, d.bias_out, d.tmp = _ptr(scale), _ptr(wf), _ptr(bias_out), _ptr(tmp)
     d.B, d.H, d.W, d.C, d.mid, d.ld1, d.tiles, d.ldcs, d.k, d.ld_scale, d.dtype = B, H, W, C_, mid, 8, tiles, ldcs, k, scale.shape[1], dtype

@@ -905,3 +905,63 @@ def test_conv_last_row_sweep_planes(geom):
     ref = F.conv2d(x.double().permute(0, 3, 1, 2), w.to(torch.bfloat16).double(), b.double(), padding=1) * scale
     ref = ref + torch.tensor(mean[:nout], dtype=torch.float64).view(1, -1, 1, 1)
     check(out.cpu(), ref.float(), "f32", f"conv_last planes {geom}", f32_tol=2e-5)
+
+
+# ------------------------------------------------------------------------------------------------
+# pooled sums of a band-sharded frame: hat_rect_sum, hat_cab_fold from supplied statistics
+# ------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("case", [(2, 40, 64, 16, 16, "bf16"), (1, 96, 1280, 16, 16, "bf16"), (1, 33, 48, 144, 144, "bf16"), (2, 19, 24, 24, 24, "f32"),
+                                  (1, 64, 256, 8, 8, "bf16")], ids=lambda c: f"B{c[0]}_{c[1]}x{c[2]}_C{c[3]}_{c[5]}")
+def test_rect_sum(case):
+    """hat_rect_sum against fp64 sums over full-width row ranges, single columns, single rows and single pixels — the
+    rectangles the band-sharded engine pools (rows a band owns; frame borders and corners for hat_cab_fold).  Many workgroups
+    at the larger sizes (cross-workgroup part through the last-block pattern); repeated calls are bit-identical."""
+    B, H, W, C, ld, dtype = case
+    dev, ops = _dev(), _ops()
+    tdt = torch.bfloat16 if dtype == "bf16" else torch.float32
+    x = q(rnd("rsx", (B, H, W, ld)), dtype)
+    xd = x.reshape(B, H * W, ld).to(tdt).to(dev).contiguous()
+    out = torch.zeros(B, 64 + 192, device=dev)
+    tmp, cnt = torch.zeros(B, 64, 256, device=dev), torch.zeros(B, dtype=torch.int32, device=dev)
+    rects = [(0, H, 0, W), (3, H - 2, 0, W), (0, H, 0, 1), (2, H, W - 1, W), (0, 1, 0, W), (H - 1, H, 0, W), (0, 1, 0, 1), (H - 1, H, W - 1, W)]
+    for r0, r1, c0, c1 in rects:
+        for rep in range(2):
+            o = torch.zeros_like(out)
+            ops.rect_sum(xd, o, tmp, cnt, B=B, W=W, ld=ld, C_=C, r0=r0, r1=r1, c0=c0, c1=c1, out_off=8)
+            torch.cuda.synchronize()
+            if rep == 0:
+                first = o.clone()
+        assert torch.equal(first, o) and int(cnt.abs().sum()) == 0
+        ref = x[:, r0:r1, c0:c1, :C].double().sum((1, 2))
+        got = o[:, 8:8 + C].double().cpu()
+        assert float((got - ref).abs().max()) <= 2e-6 * max(1.0, float(x[:, r0:r1, c0:c1].double().abs().sum((1, 2)).max())), (r0, r1, c0, c1)
+        assert float(o[:, :8].abs().max()) == 0 and float(o[:, 8 + C:].abs().max()) == 0
+
+
+def test_cab_fold_from_supplied_statistics():
+    """hat_cab_fold with `stats` (the frame-wide sums a band-sharded frame adds up from its bands' hat_rect_sum results) against
+    the same kernel computing them from c1 and its per-tile column sums: scale, folded weights and bias agree to fp32 round-off."""
+    B, H, W, C, mid = 2, 24, 40, 144, 6
+    dev, ops = _dev(), _ops()
+    dt, tdt = ops.DTYPE_CODE["bf16"], torch.bfloat16
+    c1 = q(F.gelu(rnd("cfc1", (B, H, W, mid))), "bf16")
+    w2, b2c, wk, ba = rnd("cfw2", (C, mid, 3, 3), std=(9 * mid) ** -0.5), rnd("cfb2", (C,), std=0.1), rnd("cfwk", (5,), std=1.0), rnd("cfba", (C,), std=0.1)
+    c1d = to_dev(c1, 8, tdt, dev)
+    colsum = torch.zeros(B, 1, 16, device=dev)
+    colsum[:, 0, :8] = c1d.float().sum(1)
+    res = []
+    for use_stats in (False, True):
+        scale, wf, bias_b = torch.zeros(B, 256, device=dev), torch.zeros(B, 9 * 3 * 512, dtype=tdt, device=dev), torch.zeros(B, 144, device=dev)
+        stats = None
+        if use_stats:
+            stats = torch.zeros(B, 72, device=dev)
+            tmp, cnt = torch.zeros(B, 64, 256, device=dev), torch.zeros(B, dtype=torch.int32, device=dev)
+            for off, (r0, r1, a, b_) in {0: (0, H, 0, W), 8: (0, 1, 0, W), 16: (H - 1, H, 0, W), 24: (0, H, 0, 1), 32: (0, H, W - 1, W), 40: (0, 1, 0, 1),
+                                          48: (0, 1, W - 1, W), 56: (H - 1, H, 0, 1), 64: (H - 1, H, W - 1, W)}.items():
+                ops.rect_sum(c1d, stats, tmp, cnt, B=B, W=W, ld=8, C_=8, r0=r0, r1=r1, c0=a, c1=b_, out_off=off)
+        ops.cab_fold(None if use_stats else c1d, None if use_stats else colsum, 1, 16, w2.to(dev).contiguous(), b2c.to(dev), wk.to(dev), 5, ba.to(dev),
+                     0.37, scale, wf, bias_b, None if use_stats else torch.zeros(B, 32, 16, device=dev), B=B, H=H, W=W, C_=C, mid=mid, dtype=dt, stats=stats)
+        torch.cuda.synchronize()
+        res.append((scale.cpu(), wf.float().cpu(), bias_b.cpu()))
+    for a, b_ in zip(*res):
+        assert float((a - b_).abs().max()) <= 2e-6 * max(1.0, float(a.abs().max()))
