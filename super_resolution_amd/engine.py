@@ -171,7 +171,12 @@ class HATEngine:
                                               ".mlp.fc2.weight", ".mlp.fc2.bias")]
                     # hat_ffn2 (fp16 hidden tensor, depthwise conv on the packed-fp16 VALU) where it is built; HAT_FFN_V1=1
                     # keeps the first-generation kernel for A/B runs
-                    if ops.ffn2_supported(C, hid2 // 2, dt) and os.environ.get("HAT_FFN_V1") != "1":
+                    # ... unless this block's weights could drive its FP16 hidden tensor past the FP16 range for SOME input
+                    # (pack-time worst-case bound, ops.ffn_fp16_range_bound): then the bf16-hidden kernel stays
+                    fp16_ok = ops.ffn_fp16_range_bound(fw[0], fw[1], fw[2], fw[3], *hb["n2"]) < ops.FP16_SAFE
+                    if not fp16_ok:
+                        self.fp16_fallbacks = getattr(self, "fp16_fallbacks", 0) + 1
+                    if ops.ffn2_supported(C, hid2 // 2, dt) and os.environ.get("HAT_FFN_V1") != "1" and fp16_ok:
                         hb["ffn"] = ops.pack_ffn2(*fw, dev)
                     else:
                         hb["ffn"] = ops.pack_ffn(*fw, dt, dev)

@@ -515,6 +515,27 @@ def ffn2_supported(C_: int, hid: int, dtype: int) -> bool:
     return C_ == 144 and hid % 32 == 0 and dtype == HAT_BF16
 
 
+FP16_SAFE = 6.0e4   # below _Float16's largest finite value, 65504
+
+
+def ffn_fp16_range_bound(fc1_w, fc1_b, dw_w, dw_b, ln_g, ln_b) -> float:
+    """Worst-case magnitude of anything hat_ffn2 / hat_hab_tail3 hold in FP16 — the hidden tensor u = fc1(LayerNorm2(x)), the
+    depthwise conv's outputs a and g, and the gated product a * g * sigmoid(g) — for ANY input: LayerNorm's normalised row
+    has Euclidean norm <= sqrt(C), so |u_j| <= sqrt(C) * ||W1[j] * gamma||_2 + |W1[j] . beta + b1[j]| =: U_j (Cauchy-Schwarz),
+    |a_j| <= sum_taps |wd[j, tap]| * U_j + |bd_j|, likewise g, and |a * g * sigmoid(g)| <= |a| * |g|.
+    The kernels convert to FP16 with round-toward-zero (a value past the range saturates at 65504 instead of becoming an
+    infinity) but the packed-FP16 products behind that conversion can still overflow, so the engine uses these kernels only
+    while this bound stays below FP16_SAFE and otherwise keeps hat_ffn (hidden tensor in bf16, fp32 range).  The bound is loose
+    by design (a trained HAT-S sits orders of magnitude below it: unit-variance rows, weights of norm ~1 give U ~ 12, a * g ~ 10^3)."""
+    f = lambda t: t.detach().to(torch.float64).cpu()
+    W1, b1, Wd, bd, g_, b_ = f(fc1_w), f(fc1_b), f(dw_w).reshape(-1, 9), f(dw_b), f(ln_g), f(ln_b)
+    C_ = W1.shape[1]
+    hid = W1.shape[0] // 2
+    U = (C_ ** 0.5) * (W1 * g_[None, :]).norm(dim=1) + (W1 @ b_ + b1).abs()
+    A = Wd.abs().sum(1) * U + bd.abs()
+    return float(max(U.max(), A.max(), (A[:hid] * A[hid:]).max()))
+
+
 def pack_ffn2(fc1_w, fc1_b, dw_w, dw_b, fc2_w, fc2_b, device) -> PackedFFN:
     """GatedDconvFFN weights (hat_arch.py:99-104) in hat_ffn2's layouts (include/hat_mi355x.h)."""
     f = lambda t: t.detach().to(torch.float32).cpu()

@@ -965,3 +965,75 @@ def test_cab_fold_from_supplied_statistics():
         res.append((scale.cpu(), wf.float().cpu(), bias_b.cpu()))
     for a, b_ in zip(*res):
         assert float((a - b_).abs().max()) <= 2e-6 * max(1.0, float(a.abs().max()))
+
+
+# ------------------------------------------------------------------------------------------------
+# FP16 range of the fused FFN kernels (no test drove |u| or a * SiLU(g) near the FP16 range)
+# ------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("s1", [1.0, 12.0, 22.0], ids=["unit", "u_to_300", "gate_to_3e4"])
+def test_fused_ffn2_large_hidden_magnitudes(s1):
+    """hat_ffn2 with fc1 scaled by s1 (fc2 by 1 / s1^2 so that the update stays O(1)): at s1 = 22 the hidden tensor reaches
+    |u| ~ 500 and the gated product a * SiLU(g) ~ 3e4, half the FP16 range the kernel stores them in.  As long as the
+    pack-time worst-case bound (ops.ffn_fp16_range_bound — what the engine checks before it uses the FP16 kernels) holds, the
+    result must be finite and as accurate against fp64 as at unit scale: FP16 carries 11 significant bits at every magnitude
+    of its normal range."""
+    C, B, H, W = 144, 1, 24, 32
+    dev, ops = _dev(), _ops()
+    dt = ops.DTYPE_CODE["bf16"]
+    hid = 2 * C
+    t = rnd("fr2", (B, H * W, C), std=1.5) + 0.3
+    sd = {
+        "n2.weight": 1 + rnd("fg", (C,), std=0.1), "n2.bias": rnd("fbb", (C,), std=0.1),
+        "m.fc1.weight": q(s1 * rnd("f1w", (2 * hid, C), std=C ** -0.5), "bf16"), "m.fc1.bias": s1 * rnd("f1b", (2 * hid,), std=0.1),
+        "m.dw.weight": rnd("fdw", (2 * hid, 1, 3, 3), std=1 / 3).half().float(), "m.dw.bias": rnd("fdb", (2 * hid,), std=0.1).half().float(),
+        "m.fc2.weight": (rnd("f2w", (C, hid), std=hid ** -0.5) / s1 ** 2).half().float(), "m.fc2.bias": rnd("f2b", (C,), std=0.1),
+    }
+    sdd = {k: v.double() for k, v in sd.items()}
+    m = O._ln(t.double(), sdd, "n2")
+    ref = t.double() + O.gated_dconv_ffn(m, (H, W), sdd, "m")
+    u = F.linear(m, sdd["m.fc1.weight"], sdd["m.fc1.bias"])
+    bound = ops.ffn_fp16_range_bound(sd["m.fc1.weight"], sd["m.fc1.bias"], sd["m.dw.weight"], sd["m.dw.bias"], sd["n2.weight"], sd["n2.bias"])
+    assert float(u.abs().max()) <= bound                      # the bound is a bound
+    if s1 >= 22.0:
+        assert float(u.abs().max()) >= 250.0
+    pf = ops.pack_ffn2(sd["m.fc1.weight"], sd["m.fc1.bias"], sd["m.dw.weight"], sd["m.dw.bias"], sd["m.fc2.weight"], sd["m.fc2.bias"], dev)
+    tin = t.to(dev).contiguous()
+    tout = torch.full_like(tin, 123.0)
+    dv = lambda k: sd[k].to(dev).contiguous()
+    ops.ffn(pf, tin, tout, dv("n2.weight"), dv("n2.bias"), B=B, H=H, W=W, dtype=dt)
+    torch.cuda.synchronize()
+    assert torch.isfinite(tout).all()
+    upd, upd_ref = (tout.double().cpu() - t.double()), (ref - t.double())
+    rel = float((upd - upd_ref).norm() / upd_ref.norm())
+    assert rel <= 1.2e-2, f"s1 = {s1}: hat_ffn2 update rel err {rel:.3e} (|u| max {float(u.abs().max()):.0f})"
+
+
+def test_fp16_range_bound_switches_the_engine_to_the_bf16_hidden_kernel():
+    """A HAT-S block whose fc1 is scaled until a * SiLU(g) WOULD leave the FP16 range (s1 = 300: worst-case bound 2e8, actual
+    products ~1e7): the engine must not run hat_ffn2 / hat_hab_tail3 for that block — it packs hat_ffn (bf16 hidden tensor, fp32
+    range) for it — and the whole forward stays finite and within the bf16 bar of the fp32 oracle; the other blocks keep the FP16
+    kernels."""
+    from helpers import META, max_abs, oracle_sd
+    from super_resolution_amd.registry import build_network
+    import super_resolution_amd.archs  # noqa: F401
+    dev = _dev()
+    cfg, sd = oracle_sd("hats_1g_x4")
+    sd = {k: v.clone() for k, v in sd.items()}
+    p = "layers.0.residual_group.blocks.2.mlp."
+    s1 = 300.0
+    sd[p + "fc1.weight"] *= s1
+    sd[p + "fc1.bias"] *= s1
+    sd[p + "fc2.weight"] /= s1 ** 2
+    x = synth.synth_input(7, (1, 3, 32, 48))
+    ref = O.hat_forward(x, sd, cfg)
+    net = build_network(dict(type="HAT", compute_dtype="bf16", **META["cfgs"]["hats_1g_x4"])).eval()
+    net.load_state_dict(sd, strict=True)
+    net = net.to(dev)
+    y = net(x.to(dev)).float().cpu()
+    torch.cuda.synchronize()
+    eng = net.engine()
+    assert getattr(eng, "fp16_fallbacks", 0) == 1
+    kinds = [hb["ffn"].khalf for hb in eng.layers[0]["habs"]]
+    assert kinds[2] not in ("v2", "v3") and all(k == "v2" for i, k in enumerate(kinds) if i != 2), kinds
+    assert torch.isfinite(y).all()
+    assert O.psnr_float(y, ref) >= 40.0 and max_abs(y, ref) <= 0.08, (O.psnr_float(y, ref), max_abs(y, ref))
