@@ -266,6 +266,8 @@ int hat_ocab_qkv(const HatMlpDesc* d, void* stream);
  *                         the image score tanh(0) = 0 / norm 0.  sal: (B,H,W,ldsal) T, channel 0 = the saliency map.
  *   hat_ocab_attention_kb hat_ocab_attention with `kb` applied before the relative-position bias: logit + kb, or -1e4 in
  *                         place of the logit where kb = -inf; `pad` = ceil((wse - ws) / 2), HATX's unfold padding.
+ * ldsal < 0 (dtype HAT_BF16 only): `sal` is an FP32 map of row stride -ldsal — the saliency head's last conv writes its fp32
+ * accumulators (HAT_O_NHWC_F32) so that the keys are ranked on unrounded scores; kv stays bf16.
  */
 int hat_ocab_keybias(const void* sal, int32_t ldsal, const void* kv, int32_t ldkv, float* kb, int32_t B, int32_t H, int32_t W,
                      int32_t C, int32_t ws, int32_t wse, int32_t pad, int32_t k_keep, int32_t dtype, void* stream);

@@ -209,6 +209,164 @@ __global__ __launch_bounds__(256) void ocab_attn_kernel(const T* __restrict__ q,
 }
 
 // ---------------------------------------------------------------------------------------------------------
+// Key-STREAMING form of the generic kernel, for key windows whose K / V image does not fit in LDS — the exact-fp32 path at
+// the fork's live HATX shape (hatx_arch.py:289-465 with overlap_ratio 0.6: 25 x 25 keys in 40 tiles x 30-channel heads in
+// fp32 = 169 KB).  The online softmax already consumed the keys in chunks of KCH tiles; here only ONE chunk of K and V^T is
+// resident (KCH = 10: 43 KB), staged by the whole workgroup between two barriers, and every wave carries the softmax state
+// (O, running max, partial denominator) of ALL its NQW query tiles across the chunks instead of finishing one query tile
+// after the other.  Same arithmetic, same order of the key chunks, same ODD handling (dead keys past wse^2, per-key bias
+// lookup) and the same optional HATX key bias as ocab_attn_kernel.
+// ---------------------------------------------------------------------------------------------------------
+template <typename T, int NKT, int KCH, int NQW>
+__global__ __launch_bounds__(256) void ocab_attn_stream_kernel(const T* __restrict__ q, const T* __restrict__ kv,
+                                                               const float* __restrict__ bias_rot, T* __restrict__ out, int H, int W,
+                                                               int C, int heads, int ws, int wse, int ldq, int ldkv, int ldo,
+                                                               const float* __restrict__ kb, int pad) {
+    using M = MT<T>;
+    constexpr int NK = NKT * 16, CK = KCH * 16;
+    static_assert(NKT % KCH == 0, "key tiles must split evenly into chunks");
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int d = C / heads;
+    const int dk8 = (d + 7) & ~7, dv = (d + 1) & ~1;
+    const int ldk = lds_row_elems(dk8, sizeof(T)), ldv = lds_row_elems(CK, sizeof(T));
+    T* Ks = reinterpret_cast<T*>(smem);                       // [CK][ldk]   one chunk of keys
+    T* Vt = Ks + (size_t)CK * ldk;                            // [dv][ldv]   the same chunk of V, transposed
+    float* tab = reinterpret_cast<float*>(smem + (((size_t)CK * ldk + (size_t)dv * ldv) * sizeof(T) + 15) / 16 * 16);
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = lane >> 4, c16 = lane & 15;
+    const int wx = blockIdx.x, wy = blockIdx.y;
+    const int b = blockIdx.z / heads, h = blockIdx.z - b * heads;
+    const int Mr = ws + wse - 1;
+    const size_t img = (size_t)b * H * W;
+    const float* kbw = kb ? kb + (((size_t)b * gridDim.y + wy) * gridDim.x + wx) * NK : nullptr;
+    for (int i = tid; i < Mr * Mr; i += 256) tab[i] = bias_rot[(size_t)h * Mr * Mr + i];
+
+    typename M::frag_t qf[NQW];
+    f32x4 o[NQW][2];
+    float mrun[NQW], l[NQW];
+    int qy[NQW], qx[NQW];
+    size_t qpix[NQW];
+#pragma unroll
+    for (int i = 0; i < NQW; ++i) {
+        const int qi = (wave + 4 * i) * 16 + c16;
+        qy[i] = qi / ws; qx[i] = qi - qy[i] * ws;
+        qpix[i] = img + (size_t)(wy * ws + qy[i]) * W + wx * ws + qx[i];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int c = 8 * g + j;
+            qf[i][j] = c < d ? q[qpix[i] * ldq + h * d + c] : to_T<T>(0.f);
+        }
+        o[i][0] = o[i][1] = f32x4{0.f, 0.f, 0.f, 0.f};
+        mrun[i] = -3.0e38f; l[i] = 0.f;
+    }
+    const int cpk = dk8 / 2;
+#pragma unroll 1
+    for (int ch = 0; ch < NKT / KCH; ++ch) {
+        const int kt0 = ch * KCH;
+        __syncthreads();   // every wave is done with the previous chunk (first pass: the bias table is complete)
+        for (int i = tid; i < CK * cpk; i += 256) {
+            const int kl = i / cpk, c = (i - kl * cpk) * 2, key = kt0 * 16 + kl;
+            const int kh = key / wse, kw = key - kh * wse;
+            const int y = wy * ws - pad + kh, x = wx * ws - pad + kw;
+            T k0 = to_T<T>(0.f), k1 = k0, v0 = k0, v1 = k0;
+            if (c < d && key < wse * wse && y >= 0 && y < H && x >= 0 && x < W) {
+                const T* p = kv + (img + (size_t)y * W + x) * ldkv + h * d + c;
+                k0 = p[0]; k1 = p[1];
+                v0 = p[C]; v1 = p[C + 1];
+            }
+            Ks[kl * ldk + c] = k0; Ks[kl * ldk + c + 1] = k1;
+            if (c < dv) { Vt[c * ldv + kl] = v0; Vt[(c + 1) * ldv + kl] = v1; }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < NQW; ++i) {
+            f32x4 s[KCH];
+#pragma unroll
+            for (int t = 0; t < KCH; ++t) {
+                const typename M::frag_t kf = M::load(Ks + (t * 16 + c16) * ldk + (8 * g < dk8 ? 8 * g : dk8 - 8));
+                s[t] = M::mma(kf, qf[i], f32x4{0.f, 0.f, 0.f, 0.f});
+            }
+            if (kbw != nullptr) {   // hatx_arch.py:421-449: + focus bias per key; a pruned key's logit is REPLACED by -1e4
+#pragma unroll
+                for (int t = 0; t < KCH; ++t) {
+                    const f32x4 k4 = *reinterpret_cast<const f32x4*>(kbw + (kt0 + t) * 16 + 4 * g);
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) s[t][r] = k4[r] == -INFINITY ? -1.0e4f : s[t][r] + k4[r];
+                }
+            }
+            float mx = -3.0e38f;
+#pragma unroll
+            for (int t = 0; t < KCH; ++t) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int key = (kt0 + t) * 16 + 4 * g + r;
+                    const int khr = key / wse, kwr = key - khr * wse;
+                    const int ti = min((khr - qy[i] + ws - 1) * Mr + (kwr - qx[i] + ws - 1), Mr * Mr - 1);
+                    s[t][r] = key < wse * wse ? s[t][r] + tab[ti] : -3.0e38f;
+                    mx = fmaxf(mx, s[t][r]);
+                }
+            }
+            mx = fmaxf(mx, __shfl_xor(mx, 16));
+            mx = fmaxf(mx, __shfl_xor(mx, 32));
+            const float mnew = fmaxf(mrun[i], mx);
+            const float alpha = exp_t<T>(mrun[i] - mnew);
+            mrun[i] = mnew;
+            float lsum = 0.f;
+#pragma unroll
+            for (int t = 0; t < KCH; ++t) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const float pe = exp_t<T>(s[t][r] - mnew);
+                    s[t][r] = pe;
+                    lsum += pe;
+                }
+            }
+            l[i] = l[i] * alpha + lsum;
+            o[i][0] *= alpha;
+            o[i][1] *= alpha;
+#pragma unroll
+            for (int kk = 0; kk < (KCH + 1) / 2; ++kk) {
+                const bool has_b = (2 * kk + 1 < KCH);
+                const int kb2 = has_b ? 2 * kk + 1 : 2 * kk;
+                typename M::frag_t pf;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    pf[j] = to_T<T>(s[2 * kk][j]);
+                    pf[j + 4] = has_b ? to_T<T>(s[kb2][j]) : to_T<T>(0.f);
+                }
+#pragma unroll
+                for (int ct = 0; ct < 2; ++ct) {
+                    const int vrow = (ct * 16 + c16 < dv) ? ct * 16 + c16 : dv - 1;
+                    const T* vr = Vt + (size_t)vrow * ldv + (2 * kk) * 16 + 4 * g;
+                    const Q4<T> va = *reinterpret_cast<const Q4<T>*>(vr);
+                    const Q4<T> vb = *reinterpret_cast<const Q4<T>*>(vr + (has_b ? 16 : 0));
+                    typename M::frag_t vf;
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        vf[j] = va.v[j];
+                        vf[j + 4] = has_b ? vb.v[j] : to_T<T>(0.f);
+                    }
+                    o[i][ct] = M::mma(vf, pf, o[i][ct]);
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < NQW; ++i) {
+        float ls = l[i];
+        ls += __shfl_xor(ls, 16);
+        ls += __shfl_xor(ls, 32);
+        const float inv = 1.0f / ls;
+#pragma unroll
+        for (int ct = 0; ct < 2; ++ct)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int c = ct * 16 + 4 * g + r;
+                if (c < d) out[qpix[i] * ldo + h * d + c] = to_T<T>(o[i][ct][r] * inv);
+            }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------
 // Fast path: bf16, 16x16 query windows, 24x24 key windows, head_dim 24 (HAT-S and every C = 144 model).
 // Differences from the generic kernel above, all aimed at the VALU (softmax) and LDS-store bottlenecks:
 //   * K and V are staged with 16-byte pieces, V row-major [key][32] (no 2-byte transposing stores); the A
@@ -484,7 +642,24 @@ int launch_attn(const void* q, const void* kv, const float* bias_rot, void* out,
     const int d = C / heads, dk8 = (d + 7) & ~7, dv = (d + 1) & ~1;
     const size_t kvb = ((size_t)NKT * 16 * lds_row_elems(dk8, es) + (size_t)dv * lds_row_elems(NKT * 16, es)) * es;
     const size_t lds = (kvb + 15) / 16 * 16 + (size_t)Mr * Mr * 4;
-    if (lds > HAT_LDS_MAX) return HAT_ELDS;
+    if (lds > HAT_LDS_MAX) {
+        // the key window does not fit: stream it through LDS chunk by chunk (instantiated for 16 x 16 query windows)
+        if constexpr (!SELF) {
+            if (ws != 16) return HAT_ELDS;
+            const size_t cb = ((size_t)KCH * 16 * lds_row_elems(dk8, es) + (size_t)dv * lds_row_elems(KCH * 16, es)) * es;
+            const size_t lds2 = (cb + 15) / 16 * 16 + (size_t)Mr * Mr * 4;
+            if (lds2 > HAT_LDS_MAX) return HAT_ELDS;
+            auto ks = ocab_attn_stream_kernel<T, NKT, KCH, 4>;
+            if (lds2 > 65536) {
+                hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(ks), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2);
+                if (e != hipSuccess) return (int)e;
+            }
+            HAT_LAUNCH(ks, dim3(W / ws, H / ws, B * heads), dim3(256), lds2, s, reinterpret_cast<const T*>(q), reinterpret_cast<const T*>(kv),
+                       bias_rot, reinterpret_cast<T*>(out), H, W, C, heads, ws, wse, ldq, ldkv, ldo, kb, pad);
+            return hat_check_launch();
+        }
+        return HAT_ELDS;
+    }
     auto kern = ocab_attn_kernel<T, NKT, KCH, SELF, ODD>;
     if (lds > 65536) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -503,8 +678,8 @@ int launch_attn(const void* q, const void* kv, const float* bias_rot, void* out,
 //   the lower window index (torch.topk leaves that order unspecified: DESIGN.md §7) —, kb = focus score (0 without focus
 //   head) for a kept key and -inf for a pruned one.
 // ---------------------------------------------------------------------------------------------------------
-template <typename T>
-__global__ __launch_bounds__(1024) void keybias_kernel(const T* __restrict__ sal, int ldsal, const T* __restrict__ kv, int ldkv,
+template <typename T, typename ST = T>
+__global__ __launch_bounds__(1024) void keybias_kernel(const ST* __restrict__ sal, int ldsal, const T* __restrict__ kv, int ldkv,
                                                        float* __restrict__ kb, int H, int W, int C, int ws, int wse, int pad, int k_keep) {
     __shared__ float sc[1024];
     const int nk = wse * wse, nkp = (nk + 15) & ~15, key = threadIdx.x;   // rows of nkp floats: the attention kernel's key tiles
@@ -592,10 +767,13 @@ extern "C" int hat_ocab_attention(const void* q, const void* kv, const float* bi
 extern "C" int hat_ocab_keybias(const void* sal, int32_t ldsal, const void* kv, int32_t ldkv, float* kb, int32_t B, int32_t H, int32_t W,
                                 int32_t C, int32_t ws, int32_t wse, int32_t pad, int32_t k_keep, int32_t dtype, void* stream) {
     if (!kb || (!sal && !kv) || B < 1 || ws < 1 || H % ws || W % ws || wse < ws || wse * wse > 1024 || pad < 0 || k_keep < 1) return HAT_EINVAL;
-    if ((sal && ldsal < 1) || (!sal && ldkv < C)) return HAT_EINVAL;
+    if ((sal && ldsal == 0) || (sal && ldsal < 0 && dtype != HAT_BF16) || (!sal && ldkv < C)) return HAT_EINVAL;
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     dim3 grid(W / ws, H / ws, B);
-    if (dtype == HAT_BF16)
+    if (dtype == HAT_BF16 && sal && ldsal < 0)   // ldsal < 0: the saliency map is FP32 with row stride -ldsal (the keys are ranked on it)
+        HAT_LAUNCH((keybias_kernel<bf16_t, float>), grid, dim3(1024), 0, s, reinterpret_cast<const float*>(sal), -ldsal, reinterpret_cast<const bf16_t*>(kv),
+                   ldkv, kb, H, W, C, ws, wse, pad, k_keep);
+    else if (dtype == HAT_BF16)
         HAT_LAUNCH(keybias_kernel<bf16_t>, grid, dim3(1024), 0, s, reinterpret_cast<const bf16_t*>(sal), ldsal, reinterpret_cast<const bf16_t*>(kv), ldkv, kb,
                    H, W, C, ws, wse, pad, k_keep);
     else if (dtype == HAT_F32)

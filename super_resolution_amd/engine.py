@@ -105,13 +105,23 @@ class HATEngine:
         w = sd[wkey]
         b = sd.get(bkey) if bkey else None
         o, i = w.shape[0], w.reshape(w.shape[0], -1).shape[1]
-        if ops.linear_supported(o, i, self.dtype):
-            pw = ops.pack_linear_weight(w, b, self.dtype, self.dev, scale=scale)
-            pw.frag = True
+
+        def pack(wm, bias):
+            if ops.linear_supported(wm.shape[0], wm.shape[1], self.dtype):
+                pw = ops.pack_linear_weight(wm, bias, self.dtype, self.dev, scale=scale)
+                pw.frag = True
+                return pw
+            pw = ops.pack_conv_weight(wm, bias, self.dtype, self.dev, scale=scale)
+            pw.frag = False
             return pw
-        pw = ops.pack_conv_weight(w, b, self.dtype, self.dev, scale=scale)
-        pw.frag = False
-        return pw
+        w2 = w.reshape(o, -1)
+        if w2.shape[1] == i and i > 512 and i % 16 == 0 and not ops.linear_supported(o, i, self.dtype):
+            # K too wide for any tiling (HATX's SGFN fc2 at embed_dim 180: 720 -> 180; its fp32 rows do not fit a hat_conv tile):
+            # two launches over the two halves of K, the second adding onto the first's fp32 result
+            h1, h2 = pack(w2[:, :i // 2].contiguous(), b), pack(w2[:, i // 2:].contiguous(), None)
+            h1.ksplit = h2
+            return h1
+        return pack(w, b)
 
     def _c3(self, sd, wkey, bkey):
         """Pack a CAB 3x3 conv for hat_conv3x3_small (weights resident in LDS) when instantiated, else for hat_conv."""
@@ -123,6 +133,13 @@ class HATEngine:
         return ops.pack_conv_weight(w, sd[bkey], self.dtype, self.dev)
 
     def _run_lin(self, pw, x, out, **kw):
+        h2 = getattr(pw, "ksplit", None)
+        if h2 is not None:   # out = W[:, :K/2] x[:, :K/2] + b (+ r1), then out += W[:, K/2:] x[:, K/2:]   (fp32 output only)
+            if kw.get("out_mode") != O_NHWC_F32 or kw.get("act", ACT_NONE) != ACT_NONE:
+                raise NotImplementedError("a K-split linear accumulates through its fp32 output")
+            (ops.linear if pw.frag else ops.conv)(pw, x, out, **kw)
+            (ops.linear if h2.frag else ops.conv)(h2, x.reshape(-1)[pw.cin:], out, **dict(kw, r1=out, ldr1=kw["ldo"]))
+            return
         (ops.linear if pw.frag else ops.conv)(pw, x, out, **kw)
 
     def _pack(self, sd):
@@ -286,7 +303,7 @@ class HATEngine:
         if any("esc" in L["ocab"] for L in self.layers):
             w["yesc"] = z(B, N, _r8(C))
         if self.focus:
-            w["fh"], w["sal"] = z(B, N, _r8(C // 4)), z(B, N, 8)
+            w["fh"], w["sal"] = z(B, N, _r8(C // 4)), z(B, N, 8, dtype=f)   # (the saliency map stays fp32: the keys are ranked on it)
         if self.focus or self.topk < 1.0:
             w["kb"] = z(B, (H // self.ws) * (W // self.ws), -(-(self.wse * self.wse) // 16) * 16, dtype=f)   # rows of whole key tiles
         cab2 = self.layers[0]["habs"][0]["cab2"] if self.layers and self.layers[0]["habs"] else None
@@ -446,10 +463,10 @@ class HATEngine:
                 nk, pad = self.wse * self.wse, (self.wse - ws + 1) // 2
                 if self.focus:
                     ops.conv(oc["fh0"], kv_src, w["fh"], **geo, ldx=ldc, ldo=w["fh"].shape[2], act=ACT_GELU, n_store=_r4(C // 4))
-                    ops.conv(oc["fh2"], w["fh"], w["sal"], **geo, ldx=w["fh"].shape[2], ldo=8, n_store=4)
+                    ops.conv(oc["fh2"], w["fh"], w["sal"], **geo, ldx=w["fh"].shape[2], ldo=8, n_store=4, out_mode=O_NHWC_F32)
                 k_keep = max(1, int(self.topk * nk)) if self.topk < 1.0 else nk
                 ops.ocab_keybias(w["sal"] if self.focus else None, kvbuf, w["kb"], B=B, H=H, W=W, C_=C, ws=ws, wse=self.wse, pad=pad,
-                                 k_keep=k_keep, ldsal=8, ldkv=ldkv, dtype=dt)
+                                 k_keep=k_keep, ldsal=(-8 if dt == ops.HAT_BF16 else 8), ldkv=ldkv, dtype=dt)
                 ops.ocab_attention_kb(qbuf, kvbuf, oc["bias_rot"], w["kb"], w["ao"], B=B, H=H, W=W, C_=C, heads=L["heads"], ws=ws,
                                       wse=self.wse, pad=pad, ldq=ldq, ldkv=ldkv, ldo=ldc, dtype=dt)
             else:

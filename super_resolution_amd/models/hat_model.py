@@ -30,9 +30,25 @@ class HATModel:
         if load_path:
             self.load_network(self.net_g, load_path, (opt["path"].get("strict_load_g", True)),
                               opt["path"].get("param_key_g", "params"))
-        self.net_g = self.net_g.to(self.device)
+        self.net_g = self.model_to_device(self.net_g)
         self.scale = opt.get("scale", 1)
         self.metric_results = {}
+
+    def model_to_device(self, net):
+        """basicsr BaseModel.model_to_device (base_model.py:91-104): `num_gpu > 1` wraps the network in nn.DataParallel, as the
+        reference does (one device: DataParallel forwards straight to the module; several: torch replicates the module per
+        call and every replica packs its own engine — it works, but tile_parallel / band_parallel are the multi-GPU paths of
+        this build).  `dist: true` (DistributedDataParallel) is a training-time wrapper and not needed for the test pipeline."""
+        net = net.to(self.device)
+        if self.opt.get("dist"):
+            raise NotImplementedError("dist: true wraps the network for training (DistributedDataParallel); the test pipeline "
+                                      "of this build runs with dist: false (multi-GPU inference: tile_parallel / band_parallel)")
+        if int(self.opt.get("num_gpu", 1) or 1) > 1:
+            net = torch.nn.DataParallel(net)
+        return net
+
+    def get_bare_model(self, net):  # base_model.py:106-112
+        return net.module if isinstance(net, (torch.nn.DataParallel, torch.nn.parallel.DistributedDataParallel)) else net
 
     # basicsr BaseModel.load_network (base_model.py:289-315)
     @staticmethod

@@ -72,12 +72,13 @@ _TNAME = {HAT_F32: "float", HAT_BF16: "__bf16"}
 
 class PackedConv:
     """Packed weights of one conv/linear layer (see HatConvDesc in include/hat_mi355x.h)."""
-    __slots__ = ("w", "bias", "ksize", "cin", "kpad", "nt", "n_slices", "nout", "w_bstride", "frag")
+    __slots__ = ("w", "bias", "ksize", "cin", "kpad", "nt", "n_slices", "nout", "w_bstride", "frag", "ksplit")
 
     def __init__(self, w, bias, ksize, cin, kpad, nt, n_slices, nout, w_bstride=0, frag=False):
         self.w, self.bias, self.ksize, self.cin, self.kpad = w, bias, ksize, cin, kpad
         self.nt, self.n_slices, self.nout, self.w_bstride = nt, n_slices, nout, w_bstride
         self.frag = frag  # True: MFMA-fragment order for hat_linear; False: [Npad][Kpad] rows for hat_conv
+        self.ksplit = None  # second half of a layer whose K is split over two launches (engine._lin)
 
     @property
     def npad(self):

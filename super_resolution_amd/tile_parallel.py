@@ -15,6 +15,7 @@ Two tilings:
 """
 from __future__ import annotations
 
+import collections
 import math
 from typing import Callable, List, NamedTuple, Optional, Sequence
 
@@ -107,7 +108,8 @@ def tile_forward(img: torch.Tensor, net: Callable, scale: int, tiles: Sequence[T
     return out
 
 
-_XBUF = {}
+_XBUF = collections.OrderedDict()
+_XBUF_MAX = 4   # staging pairs kept: a caller that alternates between a few frame sizes allocates each of them once
 
 
 def _exchange_buffers(shape, world, dtype, device):
@@ -116,10 +118,13 @@ def _exchange_buffers(shape, world, dtype, device):
     key = (tuple(shape), world, dtype, str(device))
     buf = _XBUF.get(key)
     if buf is None:
-        _XBUF.clear()
         send = torch.zeros(shape, dtype=dtype, device=device)
         recv = torch.empty((world * shape[0],) + tuple(shape[1:]), dtype=dtype, device=device)
         buf = _XBUF[key] = (send, recv)
+        while len(_XBUF) > _XBUF_MAX:
+            _XBUF.popitem(last=False)     # least recently used first
+    else:
+        _XBUF.move_to_end(key)
     return buf
 
 

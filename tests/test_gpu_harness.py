@@ -95,3 +95,37 @@ def test_dataparallel_wrapper_on_one_gpu():
     yd = torch.nn.DataParallel(net, device_ids=[0])(x)
     torch.cuda.synchronize()
     assert torch.equal(y, yd)
+
+
+def test_hatmodel_num_gpu_2_runs_through_dataparallel(tmp_path):
+    """`num_gpu: 2` in the options: HATModel wraps the network in nn.DataParallel exactly like basicsr's model_to_device
+    (base_model.py:91-104) and the whole test() — reflect pad, forward THROUGH the wrapper, crop — gives the bare module's
+    result; loading a state dict through the wrapper afterwards re-packs the engine (the weights key sees loads made on a
+    parent module)."""
+    if not torch.cuda.is_available():
+        pytest.skip("needs an MI355X")
+    from super_resolution_amd.models import HATModel
+    cfg = O.make_cfg(**{k: v for k, v in NET.items() if k != "type"})
+    sd = synth.synth_state_dict(O.blank_state_dict(cfg), 21)
+    ckpt = tmp_path / "net.pth"
+    torch.save({"params": sd}, ckpt)
+    base = {"name": "t", "scale": 2, "network_g": dict(NET, compute_dtype="f32"), "path": {"pretrain_network_g": str(ckpt)}}
+    m1 = HATModel(dict(base, num_gpu=1), device="cuda:0")
+    m2 = HATModel(dict(base, num_gpu=2), device="cuda:0")
+    assert isinstance(m2.net_g, torch.nn.DataParallel) and not isinstance(m1.net_g, torch.nn.DataParallel)
+    lq = synth.synth_input(31, (1, 3, 45, 38))
+    outs = []
+    for m in (m1, m2):
+        m.feed_data({"lq": lq})
+        m.test()
+        torch.cuda.synchronize()
+        outs.append(m.output.clone())
+    assert outs[0].shape == (1, 3, 90, 76) and torch.equal(outs[0], outs[1])
+    # new weights loaded THROUGH the wrapper (keys prefixed "module."): the packed engine must follow
+    sd2 = synth.synth_state_dict(O.blank_state_dict(cfg), 22)
+    m2.net_g.load_state_dict({"module." + k: v for k, v in sd2.items()})
+    m2.feed_data({"lq": lq})
+    m2.test()
+    torch.cuda.synchronize()
+    ref = O.hat_forward(O.pre_process(lq, 16)[0], sd2, cfg)[:, :, :90, :76]
+    assert float((m2.output.cpu() - ref).abs().max()) <= 1e-4

@@ -116,9 +116,8 @@ def test_hatx_focus_bias_and_topk_whole_model(dtype):
     torch.cuda.synchronize()
     if dtype == "f32":
         assert_close(y, ref, dtype, "HATX focus + top-k vs oracle (lowest-index ties)")
-    else:   # bf16 saliency values: a near-tie may prune a different key than fp32 does — a property of the precision
-        yc, rc = y.float().cpu(), ref
-        assert torch.isfinite(yc).all() and O.psnr_float(yc, rc) >= 35.0
+    else:   # (the keys are ranked on the fp32 accumulators of the saliency head's last conv: measured 45.0 dB)
+        assert_close(y, ref, dtype, "HATX focus + top-k vs oracle (lowest-index ties)")
 
 
 @pytest.mark.parametrize("mode", ["focus", "knorm"])
@@ -170,16 +169,14 @@ def test_hatx_live_shapes_whole_model(dtype):
     torch.cuda.synchronize()
     if dtype == "f32":
         assert_close(y, ref, dtype, "HATX live shapes vs oracle (lowest-index ties)")
-    else:
-        yc = y.float().cpu()
-        assert torch.isfinite(yc).all() and O.psnr_float(yc, ref) >= 35.0
+    else:   # measured 44.8 dB
+        assert_close(y, ref, dtype, "HATX live shapes vs oracle (lowest-index ties)")
 
 
 def test_hatx_live_config_dimensions_bf16_vs_oracle():
     """The fork's live training config itself (options/train/train_HAT_SRx2_ESC_OCAB_from_scratch.yml:48-81: embed_dim 180,
     window 16 with 25 x 25 key windows, six heads of 30, ESC 24 / 15 and OCAB-ESC 32 / 17, focus bias + top-k 0.6) cut to two
-    groups of one block, bf16, against the CPU oracle with the kernel's tie rule.  (The exact-fp32 path has no room for a
-    25 x 25 key window of 30-channel heads in LDS and says so.)"""
+    groups of one block, in both precisions, against the CPU oracle with the kernel's tie rule."""
     dev = _dev()
     from super_resolution_amd.registry import build_network
     kw = dict(META["cfgs"]["hatx_train_yml"], depths=[1, 1], num_heads=[6, 6])
@@ -191,12 +188,14 @@ def test_hatx_live_config_dimensions_bf16_vs_oracle():
     net.load_state_dict(sd, strict=True)
     y = net.to(dev)(x.to(dev))
     torch.cuda.synchronize()
-    yc = y.float().cpu()
-    assert torch.isfinite(yc).all() and O.psnr_float(yc, ref) >= 35.0, O.psnr_float(yc, ref)
+    assert_close(y, ref, "bf16", "HATX live config dimensions, bf16 vs oracle (lowest-index ties)")   # measured 46.4 dB
+    # the exact-fp32 path at the same shapes: a 25 x 25 window of 30-channel fp32 heads does not fit in LDS as a whole, the
+    # attention streams it through in four chunks of ten key tiles (ocab_attn_stream_kernel) — held to the fp32 bar
     net32 = build_network(dict(type="HATX", compute_dtype="f32", **kw)).eval()
     net32.load_state_dict(sd, strict=True)
-    with pytest.raises(RuntimeError):
-        net32.to(dev)(x.to(dev))
+    y32 = net32.to(dev)(x.to(dev))
+    torch.cuda.synchronize()
+    assert_close(y32, ref, "f32", "HATX live config dimensions, fp32 path vs oracle (lowest-index ties)")
 
 
 @pytest.mark.parametrize("mode", ["focus", "knorm"])

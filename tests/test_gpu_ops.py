@@ -269,7 +269,9 @@ def test_layernorm(dtype, C):
     torch.cuda.synchronize()
     check(y[:, :, :C].float(), ref, dtype, "layernorm -> T")
     check(yf, ref, "f32", "layernorm -> fp32")
-    check(gap.sum(1)[:, :gap_c] / N, ref[:, :, :gap_c].mean(1), "f32", "gap partial sums", f32_tol=1e-5)
+    # the pool adds the STORED values (T-rounded: the tensor the ESC conv then reads; a band-sharded frame pools the same rows)
+    check(gap.sum(1)[:, :gap_c] / N, y[:, :, :gap_c].double().cpu().mean(1), "f32", "gap partial sums = pool of the stored map", f32_tol=1e-5)
+    check(gap.sum(1)[:, :gap_c] / N, ref[:, :, :gap_c].mean(1), "f32", "gap partial sums vs the unrounded LayerNorm", f32_tol=1e-5 if dtype == "f32" else 1e-3)
 
 
 @pytest.mark.parametrize("geom", [(2, 24, 40, True), (1, 19, 27, False), (1, 3, 5, True)], ids=["B2_24x40_f32out", "ragged_19x27_bf16out", "15px"])
@@ -970,10 +972,11 @@ def test_cab_fold_from_supplied_statistics():
 # ------------------------------------------------------------------------------------------------
 # FP16 range of the fused FFN kernels (no test drove |u| or a * SiLU(g) near the FP16 range)
 # ------------------------------------------------------------------------------------------------
-@pytest.mark.parametrize("s1", [1.0, 12.0, 22.0], ids=["unit", "u_to_300", "gate_to_3e4"])
+@pytest.mark.parametrize("s1", [1.0, 20.0, 45.0], ids=["unit", "x20", "x45"])
 def test_fused_ffn2_large_hidden_magnitudes(s1):
-    """hat_ffn2 with fc1 scaled by s1 (fc2 by 1 / s1^2 so that the update stays O(1)): at s1 = 22 the hidden tensor reaches
-    |u| ~ 500 and the gated product a * SiLU(g) ~ 3e4, half the FP16 range the kernel stores them in.  As long as the
+    """hat_ffn2 with fc1 scaled by s1 (fc2 by 1 / s1^2 so that the update stays O(1)): at s1 = 45 the hidden tensor reaches
+    |u| ~ 200 and the gated product a * SiLU(g) more than 1e4, a sixth of the FP16 range the kernel stores them in (the
+    test states the magnitudes it reached).  As long as the
     pack-time worst-case bound (ops.ffn_fp16_range_bound — what the engine checks before it uses the FP16 kernels) holds, the
     result must be finite and as accurate against fp64 as at unit scale: FP16 carries 11 significant bits at every magnitude
     of its normal range."""
@@ -994,8 +997,11 @@ def test_fused_ffn2_large_hidden_magnitudes(s1):
     u = F.linear(m, sdd["m.fc1.weight"], sdd["m.fc1.bias"])
     bound = ops.ffn_fp16_range_bound(sd["m.fc1.weight"], sd["m.fc1.bias"], sd["m.dw.weight"], sd["m.dw.bias"], sd["n2.weight"], sd["n2.bias"])
     assert float(u.abs().max()) <= bound                      # the bound is a bound
-    if s1 >= 22.0:
-        assert float(u.abs().max()) >= 250.0
+    ud = F.conv2d(u.reshape(B, H, W, 2 * hid).permute(0, 3, 1, 2), sdd["m.dw.weight"], sdd["m.dw.bias"], padding=1, groups=2 * hid)
+    gated = float((ud[:, :hid] * F.silu(ud[:, hid:])).abs().max())
+    assert gated < 6.0e4, gated                                # inside the FP16 range: the case the kernel is specified for
+    if s1 >= 45.0:
+        assert float(u.abs().max()) >= 150.0 and gated >= 1.0e4, (float(u.abs().max()), gated)
     pf = ops.pack_ffn2(sd["m.fc1.weight"], sd["m.fc1.bias"], sd["m.dw.weight"], sd["m.dw.bias"], sd["m.fc2.weight"], sd["m.fc2.bias"], dev)
     tin = t.to(dev).contiguous()
     tout = torch.full_like(tin, 123.0)
@@ -1019,7 +1025,7 @@ def test_fp16_range_bound_switches_the_engine_to_the_bf16_hidden_kernel():
     dev = _dev()
     cfg, sd = oracle_sd("hats_1g_x4")
     sd = {k: v.clone() for k, v in sd.items()}
-    p = "layers.0.residual_group.blocks.2.mlp."
+    p = "layers.0.residual_group.blocks.1.mlp."
     s1 = 300.0
     sd[p + "fc1.weight"] *= s1
     sd[p + "fc1.bias"] *= s1
@@ -1034,6 +1040,6 @@ def test_fp16_range_bound_switches_the_engine_to_the_bf16_hidden_kernel():
     eng = net.engine()
     assert getattr(eng, "fp16_fallbacks", 0) == 1
     kinds = [hb["ffn"].khalf for hb in eng.layers[0]["habs"]]
-    assert kinds[2] not in ("v2", "v3") and all(k == "v2" for i, k in enumerate(kinds) if i != 2), kinds
+    assert kinds[1] not in ("v2", "v3") and all(k == "v2" for i, k in enumerate(kinds) if i != 1), kinds
     assert torch.isfinite(y).all()
     assert O.psnr_float(y, ref) >= 40.0 and max_abs(y, ref) <= 0.08, (O.psnr_float(y, ref), max_abs(y, ref))
