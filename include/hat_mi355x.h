@@ -429,6 +429,12 @@ typedef struct HatHabTailDesc {
     const void* wf;
     const float* bias_b;
     int32_t ldn_in;
+    /* hat_hab_tail3 at embed_dim 180 only (c1 / wf unused there): the CAB expand conv's output map and its per-sample scale */
+    int32_t ldr2;               /* row stride of r2 (elements) */
+    const void* r2;             /* (B,H,W,ldr2) T: c2 = conv3x3(c1) + b2 */
+    const float* r2scale;       /* [B][r2scale_bstride] fp32: conv_scale * ECA(c2); 1 KiB must be readable from every sample's row */
+    int32_t r2scale_bstride;
+    int32_t reserved1;
 } HatHabTailDesc;
 int hat_hab_tail(const HatHabTailDesc* d, void* stream);
 
@@ -443,6 +449,10 @@ int hat_hab_tail(const HatHabTailDesc* d, void* stream);
  *                                         depthwise conv must see as zero padding gets U = 0 exactly, hat_arch.py:112-114)
  *   dww [chunk][1024] fp16              : hat_ffn2's 640-element record zero padded to 2 KiB (two whole LDS-DMA pieces)
  *   w2f [chunk][9][64 lanes][8] fp16    : as for hat_ffn2.   b1 and dwb are not read.
+ * embed_dim 180 (HAT / HAT-L; ffn.C == 180, ffn.chunks == 12: the hidden width 360 zero padded to 384): 12 channel tiles, K = 180
+ * in 6 k-steps with the fc1 bias as column k = 180 — w1f [12][4][6][64][8], w2f [12][12][64][8], dww [12][1024], b2 a 1 KiB
+ * record — and no folded CAB (their squeeze is 60 channels wide): tB = t + W_aggr . [y16 | n[16:]] + r2scale * r2 + bias_b with
+ * w_aggr fragment packed [12][6][64][8], bias_b a 1 KiB record [256] (zero padded), r2 / r2scale as below; c1 and wf are ignored.
  */
 int hat_hab_tail3(const HatHabTailDesc* d, void* stream);
 

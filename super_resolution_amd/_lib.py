@@ -73,7 +73,8 @@ class HatFfnDesc(C.Structure):
 class HatHabTailDesc(C.Structure):
     """Mirror of `struct HatHabTailDesc` (include/hat_mi355x.h)."""
     _fields_ = [("ffn", HatFfnDesc), ("n", C.c_void_p), ("y16", C.c_void_p), ("c1", C.c_void_p), ("w_aggr", C.c_void_p),
-                ("wf", C.c_void_p), ("bias_b", C.c_void_p), ("ldn_in", C.c_int32)]
+                ("wf", C.c_void_p), ("bias_b", C.c_void_p), ("ldn_in", C.c_int32), ("ldr2", C.c_int32), ("r2", C.c_void_p),
+                ("r2scale", C.c_void_p), ("r2scale_bstride", C.c_int32), ("reserved1", C.c_int32)]
 
 
 class HatCabFoldDesc(C.Structure):

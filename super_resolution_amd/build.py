@@ -15,7 +15,7 @@ from concurrent.futures import ThreadPoolExecutor
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libhat_mi355x.so")
-SOURCES = ["hat_conv.hip", "hat_conv64r.hip", "hat_attn.hip", "hat_misc.hip", "hat_ffn.hip", "hat_ffn2.hip", "hat_tail3.hip", "hat_pw.hip", "hat_mlp.hip", "hat_cabsq.hip", "hat_esc13.hip", "hat_plan.cpp"]
+SOURCES = ["hat_conv.hip", "hat_conv64r.hip", "hat_attn.hip", "hat_misc.hip", "hat_ffn.hip", "hat_ffn2.hip", "hat_tail3.hip", "hat_tail3l.hip", "hat_pw.hip", "hat_mlp.hip", "hat_cabsq.hip", "hat_esc13.hip", "hat_plan.cpp"]
 HEADERS = [os.path.join(CSRC, "hat_common.h"), os.path.join(os.path.dirname(HERE), "include", "hat_mi355x.h")]
 FLAGS = ["-O3", "--offload-arch=gfx950", "-fPIC", "-std=c++17", "-Wall", "-Wno-unused-function"]
 

@@ -521,13 +521,17 @@ __global__ __launch_bounds__(256, 2) void tail3_kernel(const HatFfnDesc d, const
 }  // namespace
 
 #ifndef HAT_TAIL3_NO_ENTRY
+int hat_tail3_launch_c180(const HatHabTailDesc& h, void* stream);   // hat_tail3l.hip
+
 extern "C" int hat_hab_tail3(const HatHabTailDesc* dp, void* stream) {
     if (!dp) return HAT_EINVAL;
     const HatHabTailDesc& h = *dp;
     const HatFfnDesc& d = h.ffn;
-    if (!d.t_in || !d.t_out || d.t_in == d.t_out || !d.ln_g || !d.ln_b || !d.w1f || !d.dww || !d.w2f || !d.b2) return HAT_EINVAL;
+    if (!d.t_in || !d.t_out || d.t_in == d.t_out || !d.w1f || !d.dww || !d.w2f || !d.b2) return HAT_EINVAL;
     if (d.B < 1 || d.H < 1 || d.W < 1 || d.chunks < 1 || d.m_in) return HAT_EINVAL;
-    if (d.C != T3_C || d.dtype != HAT_BF16) return HAT_EUNSUPPORTED;
+    if (d.dtype != HAT_BF16) return HAT_EUNSUPPORTED;
+    if (d.C == 180) return d.chunks == 12 ? hat_tail3_launch_c180(h, stream) : HAT_EINVAL;
+    if (d.C != T3_C) return HAT_EUNSUPPORTED;
     if (d.ln1_g && (!d.ln1_b || !d.n_out || d.ldn < d.C || d.ldn % 4 || d.gap_c < 0 || d.gap_c > 16 || d.gap_c % 4)) return HAT_EINVAL;
     if (!h.n || !h.y16 || !h.c1 || !h.w_aggr || !h.wf || !h.bias_b || h.ldn_in < T3_C || h.ldn_in % 8) return HAT_EINVAL;
     const T3Aggr ag{reinterpret_cast<const bf16_t*>(h.n), reinterpret_cast<const bf16_t*>(h.y16), reinterpret_cast<const bf16_t*>(h.c1),

@@ -203,6 +203,15 @@ class HATEngine:
                     # HAT_TAIL_V2=1 keeps hat_hab_tail for A/B runs
                     if hb["tail"] and hb["ffn"].khalf == "v2" and os.environ.get("HAT_TAIL_V2") != "1":
                         hb["ffn3"] = ops.pack_ffn3(*fw, *hb["n2"], dev)
+                    # embed_dim 180 (HAT / HAT-L): hat_hab_tail3 with the CAB's c2 as a map (their squeeze is 60 wide: no fold)
+                    if ("fold" not in hb and C == 180 and fp16_ok and ops.tail3_supported(C, hid2 // 2, dt) and hb["esc"].pdim == 16
+                            and hb["esc"].aggr.frag and os.environ.get("HAT_NO_HAB_TAIL") != "1" and os.environ.get("HAT_TAIL_V2") != "1"):
+                        f3 = ops.pack_ffn3(*fw, *hb["n2"], dev)
+                        if ops.hab_tail_supported(f3, hb["esc"].aggr, w2raw.shape[1], dt):
+                            hb["ffn3"], hb["tail180"] = f3, True
+                            b256 = torch.zeros(256, **f32)
+                            b256[:C] = vec(hb["esc"].aggr_keys[1])
+                            hb["bias256"] = b256
                 L["habs"].append(hb)
             p = f"layers.{g}.residual_group.overlap_attn"
             d = C // heads
@@ -633,6 +642,22 @@ class HATEngine:
                                       float(cfg["conv_scale"]), w["eca_tmp"], w["scale"], B=B, C_=C)
                         self._esc_w(esc, w, B, bd.Hfull, W, 1, gap=gapb)
                         self._esc_conv(esc, w, w["n"], B, H, W)
+                    if hb.get("tail180") and not any(e.npad > 16 for e in [esc]):
+                        # embed_dim 180: aggregation + scaled c2 + residuals + the whole FFN in one launch (hat_hab_tail3)
+                        if i + 1 < len(L["habs"]):
+                            nxt, gap_c = L["habs"][i + 1]["n1"], L["habs"][i + 1]["esc"].pdim
+                        else:
+                            nxt, gap_c = oc["n1"], (oc["esc"].pdim if "esc" in oc else 0)
+                        if gap_c <= 16:
+                            tout = tB if t is not tB else tC
+                            ops.hab_tail(hb["ffn3"], esc.aggr, t, tout, hb["n2"][0], hb["n2"][1], n=w["n"], ldn_in=ldc, y16=w["y16"],
+                                         bias_b=hb["bias256"], B=B, H=H, W=W, dtype=dt, ln1=nxt, n_out=w["n2b"], ldn=ldc, gap_out=w["gap"],
+                                         gap_c=gap_c, n16_out=(w["n16"] if self.use_n16 else None), r2=w["c2"], ldr2=ldc,
+                                         r2scale=w["scale"], r2scale_bstride=hb["cab2"].npad)
+                            w["n"], w["n2b"] = w["n2b"], w["n"]
+                            t, have_n, nblk = tout, True, -(-H // 8) * -(-W // 16)
+                            have_n16 = self.use_n16
+                            continue
                     # t = t + aggr(cat(y16, n[pdim:])) + conv_scale * eca * c2                :236
                     # hat_linear can emit LayerNorm2 of its result as hat_ffn's m_in, turning the FFN's stage 0 into a copy.
                     # Measured at 720p HAT-S: FFN -0.034 ms, aggr +0.070 ms per block (320 more bytes per pixel to write,

@@ -578,30 +578,68 @@ def pack_ffn2(fc1_w, fc1_b, dw_w, dw_b, fc2_w, fc2_b, device) -> PackedFFN:
     return p
 
 
+def tail3_supported(C_: int, hid: int, dtype: int) -> bool:
+    """Shapes hat_hab_tail3 is built for: embed_dim 144 (hidden 288, folded CAB) and 180 (hidden 360 padded to 384, c2 as a map)."""
+    return dtype == HAT_BF16 and ((C_ == 144 and hid % 32 == 0) or (C_ == 180 and hid == 360))
+
+
 def pack_ffn3(fc1_w, fc1_b, dw_w, dw_b, fc2_w, fc2_b, ln_g, ln_b, device) -> PackedFFN:
     """GatedDconvFFN weights (hat_arch.py:99-104) + the affine part of the LayerNorm in front of them (norm2, hat_arch.py:237)
-    in hat_hab_tail3's layouts (include/hat_mi355x.h): hat_ffn2's, with
+    in hat_hab_tail3's layouts (include/hat_mi355x.h), embed_dim 144 or 180:
       * LayerNorm2's gamma folded into the fc1 columns and W1 . beta into the fc1 bias (fc1(xhat * gamma + beta) =
         (W1 diag(gamma)) xhat + (W1 beta + b1), exact in real arithmetic): the kernel normalises without an affine step;
-      * the fc1 bias as column k = 144 of the fc1 fragments;
+      * the fc1 bias as column k = C of the fc1 fragments (K = C + 1 padded to a multiple of 32);
+      * the hidden width padded to a multiple of 32 with zero units (embed_dim 180: 360 -> 384);
+      * fc1 output row (tile, n16) of a chunk computes hidden unit 8 (n16 >> 2) + 4 (tile & 1) + (n16 & 3) of its half, so that a
+        lane's 4 + 4 results of the two tiles are 16 contiguous bytes of the U row (as pack_ffn2);
       * the depthwise record of a chunk zero padded to 2 KiB and the fc2 bias to 1 KiB (every record the kernel copies is then
         a whole number of 1 KiB LDS-DMA pieces)."""
     f = lambda t: t.detach().to(torch.float32).cpu()
-    W1, gam, bet = f(fc1_w), f(ln_g), f(ln_b)
-    p = pack_ffn2(W1 * gam[None, :], f(fc1_b) + W1 @ bet, dw_w, dw_b, fc2_w, fc2_b, device)
-    chunks = p.chunks
-    w1 = p.w1f.to("cpu").reshape(chunks, 4, 5, 64, 8).clone()
-    # element (chunk, tile, ks = 4, lane, j) holds k = 128 + 8 (lane >> 4) + j of fc1 row (tile, lane & 15): k = 144 <- the bias
+    W1, b1, gam, bet = f(fc1_w), f(fc1_b), f(ln_g), f(ln_b)
+    Wd, bd, W2, b2 = f(dw_w).reshape(-1, 9), f(dw_b), f(fc2_w), f(fc2_b)
+    C_, hid = W2.shape
+    assert W1.shape == (2 * hid, C_) and C_ in (144, 180)
+    b1 = b1 + W1 @ bet
+    W1 = W1 * gam[None, :]
+    ks, nt = (C_ + 1 + 31) // 32, (C_ + 15) // 16
+    chunks = -(-hid // 32)
+    hid_p = 32 * chunks
+    z2 = lambda m, rows: torch.cat([m, torch.zeros(rows - m.shape[0], *m.shape[1:])]) if rows > m.shape[0] else m
+    W1a, W1g = z2(W1[:hid], hid_p), z2(W1[hid:], hid_p)             # (hid_p, C) each
+    b1a, b1g = z2(b1[:hid], hid_p), z2(b1[hid:], hid_p)
+    Wd10 = torch.cat([Wd, bd[:, None]], dim=1)                      # (2*hid, 10): taps 0..8 + the depthwise bias as "tap 9"
+    Wda, Wdg = z2(Wd10[:hid], hid_p), z2(Wd10[hid:], hid_p)
     lane = torch.arange(64)
-    b1 = p.b1.to("cpu").reshape(chunks, 4, 16)                      # pack_ffn2's b1c: the chunk's rows in fragment order
-    sel = (lane >> 4) == 2
-    w1[:, :, 4, sel, 0] = b1[:, :, lane[sel] & 15].to(torch.bfloat16)
-    dw = torch.zeros(chunks, 1024, dtype=torch.float16)
-    dw[:, :640] = p.dww.to("cpu").reshape(chunks, 640)
-    b2 = torch.zeros(256)
-    b2[:p.b2.numel()] = p.b2.to("cpu")
-    p.w1f, p.dww, p.b2 = w1.contiguous().to(device), dw.contiguous().to(device), b2.to(device)
-    p.khalf = "v3"
+    n16, g4, j8 = lane & 15, lane >> 4, torch.arange(8)
+    nl = torch.arange(64)                                           # fc1 output row of a chunk: tiles 0, 1 = a half; 2, 3 = gate half
+    q = 8 * ((nl & 15) >> 2) + 4 * ((nl >> 4) & 1) + (nl & 3)       # hidden unit of its half, chunk-local
+    unit = torch.arange(chunks)[:, None] * 32 + q[None, :]          # (chunks, 64)
+    half = (nl >> 5)[None, :].expand(chunks, 64)
+    Wp = torch.zeros(2, hid_p, ks * 32)
+    Wp[0, :, :C_], Wp[1, :, :C_] = W1a, W1g
+    Wp[0, :, C_], Wp[1, :, C_] = b1a, b1g                           # the bias column (the kernel keeps 1.0 in k-slot C)
+    rows = Wp[half, unit]                                           # (chunks, 64, ks*32)
+    r = rows.reshape(chunks, 4, 16, ks * 32)[:, :, n16]             # (chunks, 4, 64 lanes, K)
+    col = (torch.arange(ks)[:, None, None] * 32 + 8 * g4[None, :, None] + j8[None, None, :])   # (ks, 64, 8)
+    w1f = torch.stack([r[:, :, lane[:, None], col[k]] for k in range(ks)], dim=2)                   # (chunks, 4, ks, 64, 8)
+    # depthwise: [chunk][g][tap 0..8, bias][a-units 8g..8g+7 | gate-units 8g..8g+7], padded to 1024 elements per chunk
+    u8 = (torch.arange(chunks)[:, None, None] * 32 + 8 * torch.arange(4)[None, :, None] + j8[None, None, :])   # (chunks, 4, 8)
+    dww = torch.cat([Wda[u8].permute(0, 1, 3, 2), Wdg[u8].permute(0, 1, 3, 2)], dim=-1)         # (chunks, 4, 10, 16)
+    dw = torch.zeros(chunks, 1024)
+    dw[:, :640] = dww.reshape(chunks, 640)
+    W2p = torch.zeros(nt * 16, hid_p)
+    W2p[:C_, :hid] = W2
+    n_i = torch.arange(nt)[:, None] * 16 + n16[None, :]
+    k_i = torch.arange(chunks)[:, None, None] * 32 + (8 * g4[:, None] + j8[None, :])[None]
+    w2f = W2p[n_i[None, :, :, None].expand(chunks, nt, 64, 8), k_i[:, None].expand(chunks, nt, 64, 8)]
+    b2p = torch.zeros(256)
+    b2p[:C_] = b2
+    p = PackedFFN()
+    p.w1f = w1f.to(torch.bfloat16).contiguous().to(device)
+    p.w2f = w2f.to(torch.float16).contiguous().to(device)
+    p.dww = dw.to(torch.float16).contiguous().to(device)
+    p.b1, p.dwb, p.b2 = torch.zeros(4, device=device), torch.zeros(4, device=device), b2p.to(device)
+    p.chunks, p.C, p.hid, p.nt, p.ks, p.khalf = chunks, C_, hid, nt, ks, "v3"
     return p
 
 
@@ -657,11 +695,14 @@ def ffn(pf: PackedFFN, t_in, t_out, ln_g, ln_b, *, B: int, H: int, W: int, dtype
 
 
 def hab_tail_supported(pf: PackedFFN, aggr: PackedConv, mid: int, dtype: int) -> bool:
+    if pf.C == 180:   # hat_hab_tail3 with the CAB's c2 as a map (no fold: mid is 60)
+        return pf.khalf == "v3" and aggr.frag and aggr.nt == 12 and aggr.n_slices == 1 and aggr.kpad == 192 and dtype == HAT_BF16
     return pf.khalf in ("v2", "v3") and aggr.frag and aggr.nt == 9 and aggr.n_slices == 1 and aggr.kpad == 160 and mid <= 8 and dtype == HAT_BF16
 
 
-def hab_tail(pf: PackedFFN, aggr: PackedConv, t_in, t_out, ln_g, ln_b, *, n, ldn_in: int, y16, c1, wf, bias_b, B: int, H: int,
-             W: int, dtype: int, ln1=None, n_out=None, ldn: int = 0, gap_out=None, gap_c: int = 0, n16_out=None):
+def hab_tail(pf: PackedFFN, aggr: PackedConv, t_in, t_out, ln_g, ln_b, *, n, ldn_in: int, y16, c1=None, wf=None, bias_b, B: int, H: int,
+             W: int, dtype: int, ln1=None, n_out=None, ldn: int = 0, gap_out=None, gap_c: int = 0, n16_out=None,
+             r2=None, ldr2: int = 0, r2scale=None, r2scale_bstride: int = 0):
     """hat_hab_tail: aggregation + folded CAB + residuals + the whole gated FFN in one launch (t_in = the residual stream
     BEFORE the aggregation)."""
     lib = _lib.load()
@@ -670,6 +711,12 @@ def hab_tail(pf: PackedFFN, aggr: PackedConv, t_in, t_out, ln_g, ln_b, *, n, ldn
     d.B, d.H, d.W, d.C, d.chunks, d.dtype = B, H, W, pf.C, pf.chunks, dtype
     _fill_ffn(d, pf, t_in, t_out, ln_g, ln_b, ln1, n_out, ldn, gap_out, gap_c, n16_out=n16_out)
     h.n, h.y16, h.c1, h.w_aggr, h.wf, h.bias_b, h.ldn_in = _ptr(n), _ptr(y16), _ptr(c1), _ptr(aggr.w), _ptr(wf), _ptr(bias_b), ldn_in
+    h.r2, h.ldr2, h.r2scale, h.r2scale_bstride = _ptr(r2), ldr2, _ptr(r2scale), r2scale_bstride
+    if pf.C == 180:   # aggregation + c2 term + FFN; n, y16, c2 (T), t read once, t_out and the next LayerNorm written
+        flops = B * H * W * (2.0 * pf.C * pf.C + 2.0 * pf.C * 2 * pf.hid + 2.0 * 9 * 2 * pf.hid + 2.0 * pf.hid * pf.C)
+        nbytes = B * H * W * (2.0 * ldn_in + 32 + 2.0 * ldr2 + 4.0 * pf.C + 4.0 * pf.C + (2 * ldn if ln1 is not None else 0))
+        _timed("tail3l_kernel", flops, lambda: _lib.check(lib.hat_hab_tail3(C.byref(h), _stream()), "hat_hab_tail3"), nbytes=nbytes)
+        return
     flops = B * H * W * (2.0 * pf.C * (pf.C + 72) + 2.0 * pf.C * 2 * pf.hid + 2.0 * 9 * 2 * pf.hid + 2.0 * pf.hid * pf.C)
     # algorithmic HBM bytes per pixel: n (T), y16 (T x 16), c1 (T x 8), t (fp32) read once; t_out (fp32) and the next
     # block's LayerNorm output (T) written

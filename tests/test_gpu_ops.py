@@ -1043,3 +1043,62 @@ def test_fp16_range_bound_switches_the_engine_to_the_bf16_hidden_kernel():
     assert kinds[1] not in ("v2", "v3") and all(k == "v2" for i, k in enumerate(kinds) if i != 1), kinds
     assert torch.isfinite(y).all()
     assert O.psnr_float(y, ref) >= 40.0 and max_abs(y, ref) <= 0.08, (O.psnr_float(y, ref), max_abs(y, ref))
+
+
+@pytest.mark.parametrize("geom", [(2, 24, 40), (1, 19, 27), (1, 8, 16), (1, 35, 64)], ids=["B2_24x40", "ragged_19x27", "one_tile", "35x64"])
+def test_hab_tail3_embed_dim_180(geom):
+    """hat_hab_tail3 at embed_dim 180 (HAT / HAT-L, BASELINE configs 3-5): t + aggr([y16 | n[16:]]) + scale * c2 + bias, LayerNorm2
+    (its affine folded into fc1 at pack time), gated depthwise FFN over 360 hidden units padded to 384, residual, next LayerNorm,
+    its GAP partials and compact 16-channel copy — against an fp64 restatement (hat_arch.py:233-237, :107-119; esc_arch.py:123),
+    interior and border tiles, ragged sizes, B = 2 with per-sample scales.  Channels 180..191 of the 12th channel tile are dead
+    lanes: nothing may leak from them."""
+    B, H, W = geom
+    C, hid, ldc = 180, 360, 184
+    dev, ops = _dev(), _ops()
+    dt, tdt = ops.DTYPE_CODE["bf16"], torch.bfloat16
+    n = q(rnd("l8n", (B, H, W, C)), "bf16")
+    y16 = q(rnd("l8y", (B, H, W, 16)), "bf16")
+    c2 = q(rnd("l8c2", (B, H, W, C), std=2.0), "bf16")
+    scale = 0.05 + 0.3 * torch.rand(B, C, generator=torch.Generator().manual_seed(5))
+    t = rnd("l8t", (B, H, W, C), std=1.5) + 0.3
+    wa, ba = q(rnd("l8wa", (C, C), std=C ** -0.5), "bf16"), rnd("l8ba", (C,), std=0.1)
+    sd = {
+        "n2.weight": 1 + rnd("l8g", (C,), std=0.1), "n2.bias": rnd("l8bb", (C,), std=0.1),
+        "m.fc1.weight": rnd("l8f1w", (2 * hid, C), std=C ** -0.5), "m.fc1.bias": rnd("l8f1b", (2 * hid,), std=0.1),
+        "m.dw.weight": rnd("l8dw", (2 * hid, 1, 3, 3), std=1 / 3).half().float(), "m.dw.bias": rnd("l8db", (2 * hid,), std=0.1).half().float(),
+        "m.fc2.weight": rnd("l8f2w", (C, hid), std=hid ** -0.5).half().float(), "m.fc2.bias": rnd("l8f2b", (C,), std=0.1),
+        "n1.weight": 1 + rnd("l8g1", (C,), std=0.1), "n1.bias": rnd("l8b1", (C,), std=0.1),
+    }
+    sdd = {k: v.double() for k, v in sd.items()}
+    xin = torch.cat([y16, n[..., 16:]], -1)
+    tb = (t.double() + F.linear(xin.double(), wa.double(), ba.double()) + scale.double()[:, None, None, :] * c2.double()).reshape(B, H * W, C)
+    ref = tb + O.gated_dconv_ffn(O._ln(tb, sdd, "n2"), (H, W), sdd, "m")
+    ref_n = O._ln(ref, sdd, "n1")
+    pw = ops.pack_linear_weight(wa, ba, dt, dev)
+    assert (pw.nt, pw.kpad) == (12, 192) and ops.tail3_supported(C, hid, dt)
+    pf = ops.pack_ffn3(sd["m.fc1.weight"], sd["m.fc1.bias"], sd["m.dw.weight"], sd["m.dw.bias"], sd["m.fc2.weight"], sd["m.fc2.bias"],
+                       sd["n2.weight"], sd["n2.bias"], dev)
+    assert ops.hab_tail_supported(pf, pw, 60, dt) and pf.chunks == 12
+    nd, yd, cd = to_dev(n, ldc, tdt, dev), to_dev(y16, 16, tdt, dev), to_dev(c2, ldc, tdt, dev)
+    td = t.reshape(B, H * W, C).to(dev).contiguous()
+    scd = torch.zeros(B, 256, device=dev)
+    scd.view(-1)[:B * 192].view(B, 192)[:, :C] = scale.to(dev)      # rows of 192 floats, as hat_eca_scale writes them for C = 180
+    b256 = torch.zeros(256, device=dev)
+    b256[:C] = ba.to(dev)
+    dv = lambda k: sd[k].to(dev).contiguous()
+    tiles = -(-H // 8) * -(-W // 16)
+    out, n1, gap, n16 = torch.full_like(td, 7.0), torch.zeros(B, H * W, ldc, dtype=tdt, device=dev), torch.zeros(B, tiles, 16, device=dev), \
+        torch.zeros(B, H * W, 16, dtype=tdt, device=dev)
+    ops.hab_tail(pf, pw, td, out, dv("n2.weight"), dv("n2.bias"), n=nd, ldn_in=ldc, y16=yd, bias_b=b256, B=B, H=H, W=W, dtype=dt,
+                 ln1=(dv("n1.weight"), dv("n1.bias")), n_out=n1, ldn=ldc, gap_out=gap, gap_c=16, n16_out=n16,
+                 r2=cd, ldr2=ldc, r2scale=scd, r2scale_bstride=192)
+    torch.cuda.synchronize()
+    assert torch.isfinite(out).all()
+    upd, upd_ref = out.double().cpu() - tb, ref - tb
+    rel = float((upd - upd_ref).norm() / upd_ref.norm())
+    assert rel <= 1.2e-2, f"hab tail (embed_dim 180) FFN update rel err {rel:.3e}"
+    check(out, ref, "bf16", "hab tail 180 t_out")
+    check(n1[:, :, :C].float(), ref_n, "bf16", "hab tail 180 next-LN")
+    assert float(n1[:, :, C:].float().abs().max()) == 0.0                     # pad channels of the rows stay untouched
+    assert torch.equal(n16, n1[:, :, :16].contiguous())
+    check(gap.sum(1) / (H * W), n1[:, :, :16].float().mean(1), "f32", "hab tail 180 gap = pool of the stored rows", f32_tol=1e-5)
