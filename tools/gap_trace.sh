@@ -10,7 +10,7 @@ import csv, glob
 f = glob.glob("gpurun_out/gaptrace/*/*kernel_trace.csv")[0]
 rows = list(csv.DictReader(open(f)))
 rows.sort(key=lambda r: int(r["Start_Timestamp"]))
-tails = [r for r in rows if "ffn2_kernel" in r["Kernel_Name"]]
+tails = [r for r in rows if "tail3_kernel" in r["Kernel_Name"] or "ffn2_kernel" in r["Kernel_Name"]]
 tails = tails[-36 * 2:]          # last two frames
 gaps, between = [], {}
 for a, b in zip(tails[:-1], tails[1:]):

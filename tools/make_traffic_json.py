@@ -7,6 +7,7 @@ import csv, glob, json, re, sys, collections
 
 fdir, wdir, out, model, scale, H, W, dtype = sys.argv[1:9]
 BENCH_NAME = [  # rocprof kernel-name pattern -> the name bench.py prints
+    (r"tail3l_kernel", "tail3l_kernel"), (r"tail3_kernel", "tail3_kernel"),
     (r"ffn2_kernelILi0ELb1E|ffn2_kernel<0, true", "ffn2_kernel<aggr>"), (r"ffn2_kernel", "ffn2_kernel"),
     (r"esc13_kernel", "esc13_kernel"), (r"ffn_kernel", "ffn_kernel<__bf16>"), (r"ocab_attn", "ocab_attn_kernel<__bf16>"), (r"aggr_cab_kernel", "aggr_cab_kernel"),
     (r"pw_kernel.*ELi5E", "pw_kernel<__bf16, 9, 5>"), (r"pw_kernel.*ELi9E", "pw_kernel<__bf16, 9, 9>"),
