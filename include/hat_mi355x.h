@@ -299,6 +299,17 @@ int hat_sgfn_gate(const void* u, const float* wdw, const float* bdw, void* out, 
 int hat_ocab_attention(const void* q, const void* kv, const float* bias_rot, void* out, int32_t B, int32_t H,
                        int32_t W, int32_t C, int32_t heads, int32_t ws, int32_t wse, int32_t ldq,
                        int32_t ldkv, int32_t ldo, int32_t dtype, void* stream);
+/*
+ * hat_ocab_attention for the tuned kernel of the embed_dim-144 models (bf16, 16 x 16 windows, 24 x 24 key windows, head_dim 24;
+ * HAT_EUNSUPPORTED otherwise), with q ALREADY multiplied by head_dim^-1/2 * log2(e) — the caller folds the factor into the q
+ * projection's weights before they are rounded, so the scores are in log2 units at no extra rounding.  The kernel then carries
+ * the softmax's running offset in a spare k-slot of the QK^T MFMA (K rows hold 1.0, the query fragment -offset): p = exp2(score)
+ * with no per-score FMA and no rescale of O while every score of a 96-key chunk stays within 2^+-64 of the offset; a chunk
+ * that leaves the range re-centres the classic way.  Same result as hat_ocab_attention up to rounding (hat_arch.py:375-384).
+ */
+int hat_ocab_attention_log2(const void* q, const void* kv, const float* bias_rot, void* out, int32_t B, int32_t H, int32_t W,
+                            int32_t C, int32_t heads, int32_t ws, int32_t wse, int32_t ldq, int32_t ldkv, int32_t ldo,
+                            int32_t dtype, void* stream);
 
 /*
  * CAB squeeze conv: GELU_erf(conv3x3(x, C -> mid <= 8 channels, zero pad) + bias)   (hat_arch.py:84-85, cab.0 + GELU)

@@ -383,6 +383,13 @@ __device__ __forceinline__ float max3_raw(float a, float b, float c) {
     return r;
 }
 
+// max(|a|, |b|, |c|) in one instruction (VOP3 abs modifiers)
+__device__ __forceinline__ float max3_abs(float a, float b, float c) {
+    float r;
+    asm("v_max3_f32 %0, |%1|, |%2|, |%3|" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+    return r;
+}
+
 // D = 24 (C = 144) or 30 (C = 180, six heads): D = 30 pads K / Q to 32 channels (K rows of 4 XOR-swizzled slots), stages
 // and stores with 4-byte accesses (a head's 60-byte slice is only 4-byte aligned) and keeps the ones column at V[30].
 // WSE = 24, SELF = false: OCAB (zero-padded 24 x 24 key window around the query window).  WSE = 16, SELF = true: (shifted-)
@@ -393,7 +400,7 @@ __device__ __forceinline__ float max3_raw(float a, float b, float c) {
 // tiles (half the score registers: 80 VGPRs): the K / V image of a 24 x 24 key window (64.5 KB) limits a CU to two workgroups,
 // and sixteen waves instead of eight hide more of the softmax's latencies (0.995 -> 0.955 ms at 720p; sixteen-wave workgroups
 // measured the same as eight).
-template <int D, int WSE, bool SELF, int NTH = 256>
+template <int D, int WSE, bool SELF, int NTH = 256, bool QLOG2 = false>
 __global__ __launch_bounds__(NTH, WSE == 24 ? 2 : 4) void ocab_attn_fast_kernel(const bf16_t* __restrict__ q, const bf16_t* __restrict__ kv,
                                                                 const float* __restrict__ bias_rot, bf16_t* __restrict__ out,
                                                                 int B, int H, int W, int C, int heads, int ldq, int ldkv,
@@ -404,7 +411,14 @@ __global__ __launch_bounds__(NTH, WSE == 24 ? 2 : 4) void ocab_attn_fast_kernel(
     constexpr int CH_ROWS = KCH * 16 / WSE;  // key rows per chunk
     static_assert(KCH % 2 == 0 && KCH * 16 % WSE == 0, "a chunk is whole key rows and whole pairs of key tiles");
     static_assert(!SELF || WSE == WS, "self-attention windows coincide with the query windows");
-    constexpr int KR = D == 24 ? 24 : 32;   // K row length in LDS (elements)
+    // OFFS (the OCAB of the embed_dim-144 models): the softmax offset rides in the spare k-slots of the QK^T MFMA.  K rows
+    // are 32 channels wide with [1.0, 0 ...] in channels 24..31 of EVERY key, the query fragment carries -m (the running
+    // offset, a bf16 value, in log2 units) in channel 24, Q and the bias table are pre-multiplied by log2(e): the MFMA
+    // delivers s * log2e + bias * log2e - m, and p = exp2 of that with NO per-score FMA, no per-chunk rescale of O and no
+    // cross-lane max — while every |score - m| of a chunk stays below 64 (checked with 12 v_max3 |.| and one ballot); a chunk
+    // that leaves that range takes the classic path (re-centre, rescale O) and moves m.
+    constexpr bool OFFS = QLOG2 && D == 24 && WSE == 24 && !SELF;
+    constexpr int KR = (D == 24 && !OFFS) ? 24 : 32;   // K row length in LDS (elements)
     constexpr int ONE = D == 24 ? 24 : 30;  // V column that holds 1.0 (the softmax denominator row of O^T)
     constexpr float LOG2E = 1.4426950408889634f;
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -448,7 +462,7 @@ __global__ __launch_bounds__(NTH, WSE == 24 ? 2 : 4) void ocab_attn_fast_kernel(
 #pragma unroll
     for (int it = 0; it < NTAB; ++it) {
         const int i = tid + it * NTH;
-        tv[it] = bias_rot[(size_t)h * MR * MR + (i < MR * MR ? i : MR * MR - 1)];
+        tv[it] = bias_rot[(size_t)h * MR * MR + (i < MR * MR ? i : MR * MR - 1)] * (OFFS ? LOG2E : 1.0f);
     }
     if constexpr (D == 24) {
         // Every global load of the staging phase is issued before the first LDS store (branch-free: out-of-image keys
@@ -458,6 +472,8 @@ __global__ __launch_bounds__(NTH, WSE == 24 ? 2 : 4) void ocab_attn_fast_kernel(
             const size_t qpix = qpixel(wave + NWV * i, c16);
             qfr[i] = M::load(q + qpix * ldq + h * D + 8 * (g < 3 ? g : 2));
             if (g == 3) qfr[i] = M::zero();
+            // (OFFS: q arrives multiplied by head_dim^-1/2 * log2(e) — the factor is folded into the projection's weights
+            // before they are rounded, hat_ocab_attention_log2 — so the scores are in log2 units without another rounding)
         }
         constexpr int NIT = (NK * 4 + NTH - 1) / NTH;   // (the last pass is partial with 512 threads: clamped loads, masked stores)
         u32x4 kq[NIT], vq[NIT];
@@ -484,7 +500,12 @@ __global__ __launch_bounds__(NTH, WSE == 24 ? 2 : 4) void ocab_attn_fast_kernel(
             const u32x4 vval = c == 3 ? u32x4{0x00003F80u, 0u, 0u, 0u} : (inb ? vq[it] : zero);
             if (NIT * NTH == NK * 4 || i < NK * 4) {
                 *reinterpret_cast<u32x4*>(Vs + key * 32 + 8 * (c ^ vsw)) = vval;
-                if (c < 3) *reinterpret_cast<u32x4*>(Ks + key * KR + 8 * c) = inb ? kq[it] : zero;
+                if constexpr (OFFS) {   // 4 slots per row, XOR-swizzled by the row (conflict-free ds_read_b128); slot 3 = [1.0, 0 ...]
+                    const u32x4 kval = c == 3 ? u32x4{0x00003F80u, 0u, 0u, 0u} : (inb ? kq[it] : zero);
+                    *reinterpret_cast<u32x4*>(Ks + key * KR + 8 * (c ^ ((key >> 1) & 3))) = kval;
+                } else if (c < 3) {
+                    *reinterpret_cast<u32x4*>(Ks + key * KR + 8 * c) = inb ? kq[it] : zero;
+                }
             }
         }
     } else {
@@ -550,9 +571,10 @@ __global__ __launch_bounds__(NTH, WSE == 24 ? 2 : 4) void ocab_attn_fast_kernel(
     for (int qi4 = 0; qi4 < QPW; ++qi4) {
         const int qt = wave + NWV * qi4;
         const size_t qpix = qpixel(qt, c16);
-        const frag_t qf = qfr[qi4];
+        frag_t qf = qfr[qi4];
+        float moff = 0.f;   // OFFS: the offset currently riding in the query fragment's channel 24 (log2 units, a bf16 value)
         // D = 24: lanes g == 3 meet a zero Q fragment and re-read group 2; D = 30: 4 slots per row, XOR-swizzled by the row
-        const bf16_t* krow = D == 24 ? Ks + c16 * KR + (g < 3 ? 8 * g : 16) : Ks + c16 * KR + 8 * (g ^ ((c16 >> 1) & 3));
+        const bf16_t* krow = (D == 24 && !OFFS) ? Ks + c16 * KR + (g < 3 ? 8 * g : 16) : Ks + c16 * KR + 8 * (g ^ ((c16 >> 1) & 3));
         f32x4 o[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
         float mrun = -3.0e38f;
 #pragma unroll 1
@@ -582,24 +604,60 @@ __global__ __launch_bounds__(NTH, WSE == 24 ? 2 : 4) void ocab_attn_fast_kernel(
                     }
                 }
             }
-            float mx = -3.0e38f;
+            float c2 = 0.f;      // exponent offset applied on the VALU (classic path only)
+            bool plain = true;   // (uniform) the offset the MFMA applied is good enough for this chunk
+            if constexpr (OFFS) {
+                float am = 0.f;
 #pragma unroll
-            for (int t = 0; t < KCH; ++t) mx = max3_raw(max3_raw(mx, s[t][0], s[t][1]), s[t][2], s[t][3]);
-            mx = fmaxf(mx, __shfl_xor(mx, 16));
-            mx = fmaxf(mx, __shfl_xor(mx, 32));
-            const float mnew = fmaxf(mrun, mx);
-            const float alpha = __builtin_amdgcn_exp2f((mrun - mnew) * LOG2E);  // raw v_exp_f32: underflow flushes to 0
-            mrun = mnew;
-            const float c2 = -mnew * LOG2E;
-            o[0] *= alpha;
-            o[1] *= alpha;
+                for (int t = 0; t < KCH; ++t) am = max3_abs(max3_abs(am, s[t][0], s[t][1]), s[t][2], s[t][3]);
+                // The first chunk always centres on its row maximum (any sign: nothing is accumulated yet, and a row whose every
+                // logit lies far below zero must not underflow as a whole); later chunks re-centre only UPWARDS, when a score is
+                // more than 2^64 above the offset (a score far below it just contributes nothing).
+                plain = ch > 0 && __builtin_amdgcn_ballot_w64(am > 64.0f) == 0ull;
+                if (!plain) {
+                    asm volatile("; re-centre (rare path: keep it a branch, not predicated code)" ::: "memory");
+                    float mx = -3.0e38f;
+#pragma unroll
+                    for (int t = 0; t < KCH; ++t) mx = max3_raw(max3_raw(mx, s[t][0], s[t][1]), s[t][2], s[t][3]);
+                    mx = fmaxf(mx, __shfl_xor(mx, 16));
+                    mx = fmaxf(mx, __shfl_xor(mx, 32));
+                    const float mnew = (float)(bf16_t)(moff + (ch == 0 ? mx : fmaxf(mx, 0.f)));   // what channel 24 can hold
+                    const float delta = mnew - moff;                           // (exact: both are short; >= 0 after the first chunk)
+                    if (ch > 0) {
+                        const float alpha = __builtin_amdgcn_exp2f(-delta);    // <= 1
+                        o[0] *= alpha;
+                        o[1] *= alpha;
+                    }
+#pragma unroll
+                    for (int t = 0; t < KCH; ++t) s[t] -= f32x4{delta, delta, delta, delta};
+                    moff = mnew;
+                    if (g == 3) qf[0] = (bf16_t)(-moff);
+                }
+            } else {
+                float mx = -3.0e38f;
+#pragma unroll
+                for (int t = 0; t < KCH; ++t) mx = max3_raw(max3_raw(mx, s[t][0], s[t][1]), s[t][2], s[t][3]);
+                mx = fmaxf(mx, __shfl_xor(mx, 16));
+                mx = fmaxf(mx, __shfl_xor(mx, 32));
+                const float mnew = fmaxf(mrun, mx);
+                const float alpha = __builtin_amdgcn_exp2f((mrun - mnew) * LOG2E);  // raw v_exp_f32: underflow flushes to 0
+                mrun = mnew;
+                c2 = -mnew * LOG2E;
+                o[0] *= alpha;
+                o[1] *= alpha;
+            }
 #pragma unroll
             for (int kk = 0; kk < KCH / 2; ++kk) {
                 frag_t pf;
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
-                    pf[j] = (bf16_t)__builtin_amdgcn_exp2f(fmaf(s[2 * kk][j], LOG2E, c2));
-                    pf[4 + j] = (bf16_t)__builtin_amdgcn_exp2f(fmaf(s[2 * kk + 1][j], LOG2E, c2));
+                    if constexpr (OFFS) {
+                        pf[j] = (bf16_t)__builtin_amdgcn_exp2f(s[2 * kk][j]);
+                        pf[4 + j] = (bf16_t)__builtin_amdgcn_exp2f(s[2 * kk + 1][j]);
+                    } else {
+                        pf[j] = (bf16_t)__builtin_amdgcn_exp2f(fmaf(s[2 * kk][j], LOG2E, c2));
+                        pf[4 + j] = (bf16_t)__builtin_amdgcn_exp2f(fmaf(s[2 * kk + 1][j], LOG2E, c2));
+                    }
                 }
                 const int key0 = (kt0 + 2 * kk) * 16 + 4 * g;
 #pragma unroll
@@ -738,9 +796,9 @@ int attn_dispatch(const void* q, const void* kv, const float* bias_rot, void* ou
 }
 }  // namespace
 
-extern "C" int hat_ocab_attention(const void* q, const void* kv, const float* bias_rot, void* out, int32_t B, int32_t H,
-                                  int32_t W, int32_t C, int32_t heads, int32_t ws, int32_t wse, int32_t ldq,
-                                  int32_t ldkv, int32_t ldo, int32_t dtype, void* stream) {
+static int ocab_attention_impl(const void* q, const void* kv, const float* bias_rot, void* out, int32_t B, int32_t H,
+                               int32_t W, int32_t C, int32_t heads, int32_t ws, int32_t wse, int32_t ldq,
+                               int32_t ldkv, int32_t ldo, int32_t dtype, void* stream, bool qlog2) {
     if (!q || !kv || !bias_rot || !out || B < 1 || heads < 1 || C % heads) return HAT_EINVAL;
     if (ws < 4 || H % ws || W % ws || wse < ws || (ws * ws) % 16) return HAT_EINVAL;
     const int d = C / heads;
@@ -749,11 +807,13 @@ extern "C" int hat_ocab_attention(const void* q, const void* kv, const float* bi
     const bool fast24 = d == 24 && ldq % 8 == 0 && ldkv % 8 == 0 && ldo % 4 == 0 && C % 8 == 0;
     const bool fast30 = d == 30 && ldq % 2 == 0 && ldkv % 2 == 0 && ldo % 2 == 0 && C % 2 == 0;
     if (dtype == HAT_BF16 && ws == 16 && wse == 24 && (fast24 || fast30)) {
-        const size_t lds = (size_t)576 * (fast24 ? 24 : 32) * 2 + (size_t)576 * 32 * 2 + (size_t)39 * 39 * 4;
+        const size_t lds = (size_t)576 * ((fast24 && !qlog2) ? 24 : 32) * 2 + (size_t)576 * 32 * 2 + (size_t)39 * 39 * 4;
         static const bool w4 = getenv("HAT_ATTN_4WAVES") != nullptr;   // (A/B switch: round 1's four-wave workgroups)
-        auto kern = fast24 ? (w4 ? ocab_attn_fast_kernel<24, 24, false> : ocab_attn_fast_kernel<24, 24, false, 512>)
+        if (qlog2 && !fast24) return HAT_EUNSUPPORTED;
+        auto kern = fast24 ? (qlog2 ? ocab_attn_fast_kernel<24, 24, false, 512, true>
+                                    : (w4 ? ocab_attn_fast_kernel<24, 24, false> : ocab_attn_fast_kernel<24, 24, false, 512>))
                            : (w4 ? ocab_attn_fast_kernel<30, 24, false> : ocab_attn_fast_kernel<30, 24, false, 512>);
-        const int nth = w4 ? 256 : 512;
+        const int nth = (w4 && !qlog2) ? 256 : 512;
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return (int)e;
         const int nwin = B * (W / ws) * (H / ws);
@@ -761,7 +821,20 @@ extern "C" int hat_ocab_attention(const void* q, const void* kv, const float* bi
                    reinterpret_cast<const bf16_t*>(kv), bias_rot, reinterpret_cast<bf16_t*>(out), B, H, W, C, heads, ldq, ldkv, ldo, 0);
         return hat_check_launch();
     }
+    if (qlog2) return HAT_EUNSUPPORTED;   // only the tuned kernel takes log2-domain queries
     return attn_dispatch(q, kv, bias_rot, out, B, H, W, C, heads, ws, wse, ldq, ldkv, ldo, dtype, s, nullptr, -1);
+}
+
+extern "C" int hat_ocab_attention(const void* q, const void* kv, const float* bias_rot, void* out, int32_t B, int32_t H,
+                                  int32_t W, int32_t C, int32_t heads, int32_t ws, int32_t wse, int32_t ldq,
+                                  int32_t ldkv, int32_t ldo, int32_t dtype, void* stream) {
+    return ocab_attention_impl(q, kv, bias_rot, out, B, H, W, C, heads, ws, wse, ldq, ldkv, ldo, dtype, stream, false);
+}
+
+extern "C" int hat_ocab_attention_log2(const void* q, const void* kv, const float* bias_rot, void* out, int32_t B, int32_t H,
+                                       int32_t W, int32_t C, int32_t heads, int32_t ws, int32_t wse, int32_t ldq,
+                                       int32_t ldkv, int32_t ldo, int32_t dtype, void* stream) {
+    return ocab_attention_impl(q, kv, bias_rot, out, B, H, W, C, heads, ws, wse, ldq, ldkv, ldo, dtype, stream, true);
 }
 
 extern "C" int hat_ocab_keybias(const void* sal, int32_t ldsal, const void* kv, int32_t ldkv, float* kb, int32_t B, int32_t H, int32_t W,

@@ -145,6 +145,19 @@ __device__ __forceinline__ void store_pair_bf16(bf16_t* row, int n0, int g, f32x
     const int n = (g & 1) ? n0 + 16 + 4 * (g - 1) : n0 + 4 * g;
     *reinterpret_cast<u32x4*>(row + n) = v;
 }
+// the same with a per-lane store predicate (the lane exchange itself always runs on all 64 lanes)
+__device__ __forceinline__ void store_pair_bf16_if(bf16_t* row, int n0, int g, f32x4 a, f32x4 b, bool pred) {
+    typedef bf16_t v4 __attribute__((ext_vector_type(4)));
+    typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+    const v4 ha = {(bf16_t)a[0], (bf16_t)a[1], (bf16_t)a[2], (bf16_t)a[3]};
+    const v4 hb = {(bf16_t)b[0], (bf16_t)b[1], (bf16_t)b[2], (bf16_t)b[3]};
+    const u32x2 ua = __builtin_bit_cast(u32x2, ha), ub = __builtin_bit_cast(u32x2, hb);
+    const auto r0 = __builtin_amdgcn_permlane16_swap(ua[0], ub[0], false, false);
+    const auto r1 = __builtin_amdgcn_permlane16_swap(ua[1], ub[1], false, false);
+    const u32x4 v = {r0[0], r1[0], r0[1], r1[1]};
+    const int n = (g & 1) ? n0 + 16 + 4 * (g - 1) : n0 + 4 * g;
+    if (pred) *reinterpret_cast<u32x4*>(row + n) = v;
+}
 
 // LDS row stride (in elements) for rows of `n` elements of size `es`, for MFMA operand images read by ds_read_b128
 // with lane (c16, g) -> row base + c16, 16-byte slot k0 + g (bf16) or k0 + 2g (+1) (f32).  The instruction is serviced

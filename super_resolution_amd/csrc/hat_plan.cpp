@@ -56,7 +56,7 @@ struct Reader {
 // function ids: the order of this table is the file format (super_resolution_amd/plan.py FN_IDS mirrors it)
 const char* const FN_NAMES[] = {"hat_conv", "hat_linear", "hat_conv3x3_small", "hat_cab_fold", "hat_aggr_cab", "hat_ffn", "hat_ffn2",
                                 "hat_hab_tail", "hat_layernorm", "hat_esc_weights", "hat_eca_scale", "hat_dwconv_gate", "hat_sgfn_gate",
-                                "hat_ocab_attention", "hat_window_attention", "hat_cab_squeeze", "hat_conv3x3_to_planes", "hat_add_f32", "hat_esc_conv13", "hat_ocab_keybias", "hat_ocab_attention_kb", "hat_ocab_mlp", "hat_ocab_qkv", "hat_hab_tail3"};
+                                "hat_ocab_attention", "hat_window_attention", "hat_cab_squeeze", "hat_conv3x3_to_planes", "hat_add_f32", "hat_esc_conv13", "hat_ocab_keybias", "hat_ocab_attention_kb", "hat_ocab_mlp", "hat_ocab_qkv", "hat_hab_tail3", "hat_ocab_attention_log2"};
 constexpr uint32_t N_FN = sizeof(FN_NAMES) / sizeof(FN_NAMES[0]);
 
 struct Resolved {   // argument values of one call with the pointers patched
@@ -151,6 +151,10 @@ int dispatch(Resolved& r) {
         case 21: return n == 2 ? hat_ocab_mlp((const HatMlpDesc*)r.P(0), r.P(1)) : HAT_EINVAL;
         case 22: return n == 2 ? hat_ocab_qkv((const HatMlpDesc*)r.P(0), r.P(1)) : HAT_EINVAL;
         case 23: return n == 2 ? hat_hab_tail3((const HatHabTailDesc*)r.P(0), r.P(1)) : HAT_EINVAL;
+        case 24:
+            return n == 16 ? hat_ocab_attention_log2(r.P(0), r.P(1), (const float*)r.P(2), r.P(3), r.I(4), r.I(5), r.I(6), r.I(7), r.I(8), r.I(9), r.I(10),
+                                                     r.I(11), r.I(12), r.I(13), r.I(14), r.P(15))
+                           : HAT_EINVAL;
         default: return HAT_EUNSUPPORTED;
     }
 }

@@ -477,16 +477,31 @@ __global__ __launch_bounds__(256, 2) void tail3_kernel(const HatFfnDesc d, const
             q += __shfl_xor(q, 16); q += __shfl_xor(q, 32);
             const float rstd = 1.0f / sqrtf(q / (float)C + 1e-5f);
             bf16_t* nout = reinterpret_cast<bf16_t*>(d.n_out) + ((size_t)b * H * W + pix) * d.ldn;
-#pragma unroll
-            for (int nt = 0; nt < NT; ++nt) {
+            auto lnv = [&](int nt) {
                 f32x4 o;
 #pragma unroll
                 for (int r = 0; r < 4; ++r) o[r] = (acc2[nt][pt][r] - mean) * rstd * g1v[nt][r] + bt1v[nt][r];
+                return o;
+            };
+            // the bf16 rows leave as 16-byte stores of n-tile pairs (store_pair_bf16: 64 contiguous bytes per pixel and
+            // instruction instead of 32) when the rows are 16-byte aligned; tile 8 and the compact copy as 8-byte stores
+            const bool pair16 = d.ldn % 8 == 0 && reinterpret_cast<uintptr_t>(d.n_out) % 16 == 0;   // (uniform)
+            {
+                const f32x4 o0 = lnv(0);
                 if (valid) {
-                    Vec4<bf16_t>::store(nout + nt * 16 + 4 * g, o);
-                    if (nt == 0 && 4 * g < d.gap_c) gapv += as_stored<bf16_t>(o);
-                    if (nt == 0 && d.n16_out != nullptr)   // compact copy of channels 0..15 for the next block's ESC conv
-                        Vec4<bf16_t>::store(reinterpret_cast<bf16_t*>(d.n16_out) + ((size_t)b * H * W + pix) * 16 + 4 * g, o);
+                    if (4 * g < d.gap_c) gapv += as_stored<bf16_t>(o0);
+                    if (d.n16_out != nullptr)   // compact copy of channels 0..15 for the next block's ESC conv
+                        Vec4<bf16_t>::store(reinterpret_cast<bf16_t*>(d.n16_out) + ((size_t)b * H * W + pix) * 16 + 4 * g, o0);
+                }
+                if (pair16) {
+                    store_pair_bf16_if(nout, 0, g, o0, lnv(1), valid);
+#pragma unroll
+                    for (int nt = 2; nt + 1 < NT; nt += 2) store_pair_bf16_if(nout, nt * 16, g, lnv(nt), lnv(nt + 1), valid);
+                    if (valid) Vec4<bf16_t>::store(nout + (NT - 1) * 16 + 4 * g, lnv(NT - 1));
+                } else if (valid) {
+                    Vec4<bf16_t>::store(nout + 4 * g, o0);
+#pragma unroll
+                    for (int nt = 1; nt < NT; ++nt) Vec4<bf16_t>::store(nout + nt * 16 + 4 * g, lnv(nt));
                 }
             }
         }

@@ -216,6 +216,12 @@ class HATEngine:
             p = f"layers.{g}.residual_group.overlap_attn"
             d = C // heads
             qscale = cfg.get("qk_scale") or d ** -0.5
+            # the tuned OCAB kernel of the embed_dim-144 models takes its queries in log2 units: fold log2(e) into the q
+            # projection too (before the weights are rounded), not into the kernel (HAT_NO_ATTN_LOG2=1: the round-2 kernel)
+            qlog2 = (ops.ocab_attention_log2_supported(C, heads, self.ws, self.wse, dt) and not (self.focus or self.topk < 1.0)
+                     and os.environ.get("HAT_NO_ATTN_LOG2") != "1" and d % 2 == 0 and _r8(C) == C)
+            if qlog2:
+                qscale = qscale * ops.LOG2E
             table = sd[p + ".relative_position_bias_table"].detach().to(torch.float32).cpu()  # (M*M, heads)
             oc = {
                 "n1": (vec(p + ".norm1.weight"), vec(p + ".norm1.bias")),
@@ -231,6 +237,7 @@ class HATEngine:
                          if ops.ocab_mlp_supported(C, sd[p + ".mlp.0.weight"].shape[0], dt) and _r8(C) == C
                          and not os.environ.get("HAT_NO_OCAB_MLP") else None),
                 "bias_rot": table[rot].t().contiguous().to(dev),  # [heads][M*M]
+                "qlog2": qlog2,
             }
             # q and kv projections in one launch (both read LayerNorm1's output) where hat_ocab_qkv is built and the OCAB has
             # no ESC on its key / value path (HAT_NO_OCAB_QKV=1: two hat_linear launches on two streams)
@@ -480,7 +487,7 @@ class HATEngine:
                                       wse=self.wse, pad=pad, ldq=ldq, ldkv=ldkv, ldo=ldc, dtype=dt)
             else:
                 ops.ocab_attention(qbuf, kvbuf, oc["bias_rot"], w["ao"], B=B, H=H, W=W, C_=C, heads=L["heads"], ws=ws,
-                                   wse=self.wse, ldq=ldq, ldkv=ldkv, ldo=ldc, dtype=dt)
+                                   wse=self.wse, ldq=ldq, ldkv=ldkv, ldo=ldc, dtype=dt, q_log2=oc["qlog2"])
             tout = tB if t is tA else t  # never write the RHAG input buffer
             if oc["proj"].frag:  # norm2 (:306) rides on the projection's epilogue
                 self._run_lin(oc["proj"], w["ao"], tout, **geo, ldx=ldc, ldo=C, out_mode=O_NHWC_F32, r1=t, ldr1=C,

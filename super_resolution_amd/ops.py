@@ -355,12 +355,21 @@ def sgfn_gate(u, wdw, bdw, out, *, B: int, H: int, W: int, half: int, ldu: int, 
         lib.hat_sgfn_gate(_ptr(u), _ptr(wdw), _ptr(bdw), _ptr(out), B, H, W, half, ldu, ldo, dtype, _stream()), "hat_sgfn_gate"))
 
 
+LOG2E = 1.4426950408889634
+
+
+def ocab_attention_log2_supported(C_: int, heads: int, ws: int, wse: int, dtype: int) -> bool:
+    """Shapes hat_ocab_attention_log2 (softmax offset in a spare k-slot; q pre-multiplied by log2 e) is built for."""
+    return dtype == HAT_BF16 and C_ % heads == 0 and C_ // heads == 24 and ws == 16 and wse == 24 and C_ % 8 == 0
+
+
 def ocab_attention(q, kv, bias_rot, out, *, B: int, H: int, W: int, C_: int, heads: int, ws: int, wse: int, ldq: int,
-                   ldkv: int, ldo: int, dtype: int):
+                   ldkv: int, ldo: int, dtype: int, q_log2: bool = False):
+    """q_log2: q was projected with head_dim^-1/2 * log2(e) folded into its weights (hat_ocab_attention_log2)."""
     lib = _lib.load()
+    fn, nm = (lib.hat_ocab_attention_log2, "hat_ocab_attention_log2") if q_log2 else (lib.hat_ocab_attention, "hat_ocab_attention")
     _timed(f"ocab_attn_kernel<{_TNAME[dtype]}>", 2.0 * 2 * wse * wse * C_ * B * H * W, lambda: _lib.check(
-        lib.hat_ocab_attention(_ptr(q), _ptr(kv), _ptr(bias_rot), _ptr(out), B, H, W, C_, heads, ws, wse, ldq, ldkv, ldo, dtype,
-                               _stream()), "hat_ocab_attention"))
+        fn(_ptr(q), _ptr(kv), _ptr(bias_rot), _ptr(out), B, H, W, C_, heads, ws, wse, ldq, ldkv, ldo, dtype, _stream()), nm))
 
 
 # ------------------------------------------------------------------------------------------------

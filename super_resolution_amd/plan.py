@@ -33,7 +33,7 @@ from . import _lib
 # function ids = index in this list (csrc/hat_plan.cpp FN_NAMES mirrors it)
 FN_IDS = ["hat_conv", "hat_linear", "hat_conv3x3_small", "hat_cab_fold", "hat_aggr_cab", "hat_ffn", "hat_ffn2", "hat_hab_tail",
           "hat_layernorm", "hat_esc_weights", "hat_eca_scale", "hat_dwconv_gate", "hat_sgfn_gate", "hat_ocab_attention",
-          "hat_window_attention", "hat_cab_squeeze", "hat_conv3x3_to_planes", "hat_add_f32", "hat_esc_conv13", "hat_ocab_keybias", "hat_ocab_attention_kb", "hat_ocab_mlp", "hat_ocab_qkv", "hat_hab_tail3"]
+          "hat_window_attention", "hat_cab_squeeze", "hat_conv3x3_to_planes", "hat_add_f32", "hat_esc_conv13", "hat_ocab_keybias", "hat_ocab_attention_kb", "hat_ocab_mlp", "hat_ocab_qkv", "hat_hab_tail3", "hat_ocab_attention_log2"]
 ARG_INT, ARG_FLOAT, ARG_PTR, ARG_STRUCT, ARG_HOST, ARG_STREAM = range(6)
 BUF_CONST, BUF_SCRATCH, BUF_INPUT, BUF_OUTPUT = range(4)
 NULL_BUF = 0xFFFFFFFF

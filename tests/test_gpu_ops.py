@@ -1102,3 +1102,38 @@ def test_hab_tail3_embed_dim_180(geom):
     assert float(n1[:, :, C:].float().abs().max()) == 0.0                     # pad channels of the rows stay untouched
     assert torch.equal(n16, n1[:, :, :16].contiguous())
     check(gap.sum(1) / (H * W), n1[:, :, :16].float().mean(1), "f32", "hab tail 180 gap = pool of the stored rows", f32_tol=1e-5)
+
+
+@pytest.mark.parametrize("case", ["late_spike", "first_chunk_huge", "all_very_negative", "mixed"])
+def test_ocab_attention_fast_kernel_offset_range(case):
+    """The bf16 OCAB kernel of the embed_dim-144 models carries the softmax offset in a spare k-slot of the QK^T MFMA and only
+    re-centres when a chunk's scores leave +-64 (log2 units) around it.  Logits far outside that range — a spike in the last key
+    chunk, a first chunk hundreds above the rest, every logit far below zero, and all of it at once across windows — must take
+    the re-centring path and still match the fp64 softmax (hat_arch.py:375-384) at the bf16 bar."""
+    dev, ops = _dev(), _ops()
+    ws, heads, C, H, W, B = 16, 6, 144, 32, 48, 1
+    wse, d = 24, 24
+    qv = q(rnd("oq", (B, H, W, C)) * d ** -0.5, "bf16")
+    kv = rnd("okv", (B, H, W, 2 * C))
+    table = rnd("otab", ((ws + wse - 1) ** 2, heads), std=0.5)
+    if case in ("late_spike", "mixed"):
+        kv[0, 19, 19, :C] *= 60.0          # bottom-right of window (0, 0)'s key window: its last key chunk
+    if case in ("first_chunk_huge", "mixed"):
+        kv[0, 12:14, 16:40, :C] *= 45.0     # first key rows of the windows in window row 1
+    if case == "all_very_negative":
+        table = table - 150.0               # every logit ~ -150: exp2 of the raw scores underflows without a re-centre
+    kv = q(kv, "bf16")
+    ref = O.ocab_attention(qv.double(), kv[..., :C].double(), kv[..., C:].double(), table.double(), O.rpi_oca(ws, 0.5), ws, wse, heads, 1.0)
+    M = ws + wse - 1
+    rot = (torch.arange(M * M) + (ws - wse + 1 - (ws - 1)) * (M + 1)) % (M * M)
+    out = torch.zeros(B, H * W, C, dtype=torch.bfloat16, device=dev)
+    # the log2 entry takes q * log2(e), rounded ONCE (the engine folds the factor into the projection's weights): the reference
+    # is the softmax of exactly those queries
+    ql = q(qv * ops.LOG2E, "bf16")
+    ref = O.ocab_attention((ql / ops.LOG2E).double(), kv[..., :C].double(), kv[..., C:].double(), table.double(), O.rpi_oca(ws, 0.5), ws, wse, heads, 1.0)
+    assert ops.ocab_attention_log2_supported(C, heads, ws, wse, ops.HAT_BF16)
+    ops.ocab_attention(to_dev(ql, C, torch.bfloat16, dev), to_dev(kv, 2 * C, torch.bfloat16, dev), table[rot].t().contiguous().to(dev),
+                       out, B=B, H=H, W=W, C_=C, heads=heads, ws=ws, wse=wse, ldq=C, ldkv=2 * C, ldo=C, dtype=ops.HAT_BF16, q_log2=True)
+    torch.cuda.synchronize()
+    assert torch.isfinite(out.float()).all()
+    check(out.float().reshape(B, H, W, C), ref, "bf16", f"fast OCAB kernel (log2 queries), {case}")
