@@ -14,7 +14,7 @@ and the bands together compute exactly the unsharded forward:
     under the aggregation's halo row) = 2.1 MB per side at 720p; per group four rows for the OCAB's key windows and one for
     the group conv; eight rows once before the five convs that end the network;
   * the two global pools become sums over the band's OWN rows (`hat_rect_sum`) added over the bands
-    (`("reduce", local, glob, n)`): 16 floats and 72 floats per HAB (fp32 path: 16 and C).
+    (`("reduce", [(local, glob, n) ...])`): 16 + 72 floats per HAB in ONE reduce (fp32 / embed_dim-180 path: 16 + C).
 
 `HATEngine._forward_gen(x_band, band=...)` is the per-band forward as a generator that yields those two requests; this
 module holds the two drivers that answer them:
@@ -76,6 +76,11 @@ def make_bands(H: int, n: int, window: int = 16, ghost: int = GHOST) -> List[Ban
     return out
 
 
+def _pairs(req):
+    """A reduce request's (local, glob, n) triples: ("reduce", [(local, glob, n), ...]) or the single-vector ("reduce", local, glob, n)."""
+    return req[1] if isinstance(req[1], (list, tuple)) else [(req[1], req[2], req[3])]
+
+
 def _rows(t: torch.Tensor, B: int, hb: int) -> torch.Tensor:
     """(B, hb, row_elems) view of a channel-last map (B, hb*W, ld) or (B, hb*W*ld)."""
     return t.reshape(B, hb, -1)
@@ -118,13 +123,13 @@ def run_lockstep(gens: Sequence[Generator], bands: Sequence[Band], B: int, add: 
                         l = bands[i + 1]
                         views[i][:, b.lo + b.own:b.lo + b.own + depth].copy_(views[i + 1][:, l.lo:l.lo + depth])
         elif kind == "reduce":
-            m = reqs[0][3]
-            glob0 = reqs[0][2]
-            add(reqs[0][1], reqs[1][1], glob0, m) if n > 1 else glob0[:, :m].copy_(reqs[0][1][:, :m])
-            for i in range(2, n):
-                add(glob0, reqs[i][1], glob0, m)
-            for i in range(1, n):
-                reqs[i][2][:, :m].copy_(glob0[:, :m])
+            for k in range(len(_pairs(reqs[0]))):
+                loc0, glob0, m = _pairs(reqs[0])[k]
+                add(loc0, _pairs(reqs[1])[k][0], glob0, m) if n > 1 else glob0[:, :m].copy_(loc0[:, :m])
+                for i in range(2, n):
+                    add(glob0, _pairs(reqs[i])[k][0], glob0, m)
+                for i in range(1, n):
+                    _pairs(reqs[i])[k][1][:, :m].copy_(glob0[:, :m])
         else:
             raise RuntimeError(f"unknown band request {kind!r}")
         for i, g in enumerate(gens):
@@ -199,13 +204,16 @@ def run_distributed(gen: Generator, band: Band, bands: Sequence[Band], B: int, g
                     w.wait()
             for v, a, b_, recv in recvs:
                 v[:, a:b_].copy_(recv)
-        elif req[0] == "reduce":
-            _, local, glob, m = req
-            buf = local[:, :m].contiguous()
+        elif req[0] == "reduce":     # all of the request's vectors in ONE all-reduce
+            pairs = _pairs(req)
+            buf = torch.cat([loc[:, :m] for loc, _, m in pairs], dim=1).contiguous()
             if stage_on_host:
                 buf = buf.cpu()
             dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=group)
-            glob[:, :m].copy_(buf)
+            o = 0
+            for _, glob, m in pairs:
+                glob[:, :m].copy_(buf[:, o:o + m])
+                o += m
         else:
             raise RuntimeError(f"unknown band request {req[0]!r}")
         try:

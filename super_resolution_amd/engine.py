@@ -553,8 +553,7 @@ class HATEngine:
                         pooled(w["n16"], 16, esc.pdim, w["gstat_l"])
                     else:
                         pooled(w["n"], ldc, esc.pdim, w["gstat_l"])
-                    yield ("reduce", w["gstat_l"], w["gstat_g"], esc.pdim)
-                    gapb = w["gstat_g"]
+                    gapb = w["gstat_g"]    # (summed over the bands together with the CAB pool below: ONE reduce per HAB)
                 mid = hb["cab0"].nout
                 if "fold" in hb:
                     # c2 = conv3x3(c1) never exists: its ECA pooling follows from the sums of c1 (hat_cab_fold) and the
@@ -593,7 +592,7 @@ class HATEngine:
                             pooled(w["c1"], 8, 8, st, 16, r0=lo + own - 1, r1=lo + own)
                             pooled(w["c1"], 8, 8, st, 56, r0=lo + own - 1, r1=lo + own, c0=0, c1=1)
                             pooled(w["c1"], 8, 8, st, 64, r0=lo + own - 1, r1=lo + own, c0=W - 1, c1=W)
-                        yield ("reduce", st, w["cstat_g"], 72)
+                        yield ("reduce", [(w["gstat_l"], w["gstat_g"], esc.pdim), (st, w["cstat_g"], 72)])
                         ops.cab_fold(None, None, 1, hb["cab0"].npad, fo["w2"], fo["b2"], hb["eca_w"], hb["eca_w"].numel(), fo["ba"],
                                      float(cfg["conv_scale"]), w["scale"], w["wf"], w["bias_b"], None, B=B, H=bd.Hfull, W=W, C_=C,
                                      mid=mid, dtype=dt, stats=w["cstat_g"])
@@ -644,7 +643,7 @@ class HATEngine:
                         npd = hb["cab2"].npad
                         el, eg = (w[k].view(-1)[:B * npd].view(B, npd) for k in ("estat_l", "estat_g"))
                         pooled(w["c2"], ldc, C, el)
-                        yield ("reduce", el, eg, _r4(C))
+                        yield ("reduce", [(w["gstat_l"], w["gstat_g"], esc.pdim), (el, eg, _r4(C))])
                         ops.eca_scale(eg, 1, npd, npix_full, hb["eca_w"], hb["eca_w"].numel(),
                                       float(cfg["conv_scale"]), w["eca_tmp"], w["scale"], B=B, C_=C)
                         self._esc_w(esc, w, B, bd.Hfull, W, 1, gap=gapb)
