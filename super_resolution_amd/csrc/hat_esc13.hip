@@ -10,15 +10,17 @@
 //     from a zero page);
 //   * the haloed input tile (44 x 44 pixels x 16 channels, 32 bytes per pixel: lane (p, g) -> pixel p + tap column, half
 //     g & 1 is conflict-free for ds_read_b128) is resident too: no barrier inside the K loop;
-//   * a wave owns two output rows x 32 columns and sweeps the tap ROWS for a fixed column pair: the input-row fragment that
-//     output row 1 uses for tap row dy is the one output row 0 needs for tap row dy + 1, so 14 row fragments feed 26
-//     k-steps: 0.79 KB of LDS reads per MFMA instead of 1.5;
-//   * 16 waves per workgroup (4 per SIMD, < 64 registers each) hide the LDS latency.
+//   * a wave owns RW output rows x 32 columns and sweeps the tap ROWS for a fixed column pair: the input-row fragment that
+//     output row j + 1 uses for tap row dy is the one output row j needs for tap row dy + 1, so RW + 12 row fragments (x 2
+//     column tiles) and 13 weight fragments feed 13 * RW * 2 MFMAs.  RW = 2 (sixteen waves, round 2): 0.79 KB of LDS reads
+//     per MFMA, the LDS array 75 % busy at the MFMA rate; RW = 4 (eight waves, two per SIMD): 0.43 KB per MFMA.
+#include <cstdlib>
+
 #include "hat_common.h"
 
 namespace {
 
-constexpr int E_TR = 32, E_TC = 32, E_WAVES = 16, E_HALO = 6;
+constexpr int E_TR = 32, E_TC = 32, E_HALO = 6;
 constexpr int E_HR = E_TR + 2 * E_HALO, E_HC = E_TC + 2 * E_HALO;      // 44 x 44 haloed pixels
 constexpr int E_NFRAG = 7 * 13;
 constexpr int E_X_OFF = E_NFRAG * 1024;                                  // 93184
@@ -26,9 +28,11 @@ constexpr int E_LDS = E_X_OFF + E_HR * E_HC * 32 + 64;                   // 1552
 
 __device__ __attribute__((aligned(16))) unsigned hat_esc13_zero_page[4] = {0, 0, 0, 0};
 
-__global__ __launch_bounds__(E_WAVES * 64) void esc13_kernel(const bf16_t* __restrict__ x, int ldx, const bf16_t* __restrict__ wp, int Kpad,
+template <int RW>
+__global__ __launch_bounds__((E_TR / RW) * 64) void esc13_kernel(const bf16_t* __restrict__ x, int ldx, const bf16_t* __restrict__ wp, int Kpad,
                                                              bf16_t* __restrict__ y16, int H, int W, int tiles_x, int ntiles) {
     typedef __bf16 bf8 __attribute__((ext_vector_type(8)));
+    constexpr int E_WAVES = E_TR / RW;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     typedef __attribute__((address_space(3))) char lds_char;
     const unsigned lds0 = (unsigned)(uintptr_t)(lds_char*)smem;
@@ -49,7 +53,7 @@ __global__ __launch_bounds__(E_WAVES * 64) void esc13_kernel(const bf16_t* __res
         }
         if (tid < 4) *reinterpret_cast<u32x4*>(smem + E_LDS - 64 + tid * 16) = u32x4{0u, 0u, 0u, 0u};
     }
-    const int r0 = 2 * wave;
+    const int r0 = RW * wave;
     // lane (p, g): pixel column c16 + (g >> 1) (the second tap of a pair is one column further), channel half g & 1
     const unsigned xbase = lds0 + E_X_OFF + (unsigned)((r0 * E_HC + c16 + (g >> 1)) * 32 + (g & 1) * 16);
     const unsigned abase = lds0 + (unsigned)lane * 16u;
@@ -83,33 +87,54 @@ __global__ __launch_bounds__(E_WAVES * 64) void esc13_kernel(const bf16_t* __res
         __syncthreads();   // (first tile: also drains the weight copy)
         fetch(t + gridDim.x);   // in flight during the K loop (clamped to a valid tile past the end)
 
-        f32x4 acc[2][2];
+        f32x4 acc[RW][2];
 #pragma unroll
-        for (int pt = 0; pt < 2; ++pt)
+        for (int pt = 0; pt < RW; ++pt)
 #pragma unroll
             for (int ct = 0; ct < 2; ++ct) acc[pt][ct] = f32x4{0.f, 0.f, 0.f, 0.f};
         auto ldb = [&](int rr, int dxp, int ct) {
             return __builtin_bit_cast(bf8, *(__attribute__((address_space(3))) const u32x4*)(uintptr_t)(xbase + (unsigned)((rr * E_HC) * 32 + dxp * 64 + ct * 512)));
         };
+        // Operand reads run ONE tap row ahead of their MFMAs and the scheduler may not move anything across a tap row
+        // (sched_barrier): left alone it hoists a column pair's 45 reads above the first MFMA — 144 registers for RW = 4,
+        // where 128 is what lets two of these waves share a SIMD with a wave of the CAB squeeze conv (hat_cabsq.hip).
+        auto lda = [&](int dxp, int dy) {
+            return __builtin_bit_cast(bf8, *(__attribute__((address_space(3))) const u32x4*)(uintptr_t)(abase + (unsigned)((dxp * 13 + dy) * 1024)));
+        };
+        bf8 rowf[7][RW + 12][2];   // [column pair][input row r0 + i][column tile] (fully unrolled: RW + 1 rows live at a time)
+        bf8 afr[7][13];
+        constexpr int PRE = RW < 2 ? RW : 2;   // rows of the next column pair requested during the last tap row of this one
+        afr[0][0] = lda(0, 0);
+#pragma unroll
+        for (int j = 0; j < PRE; ++j) { rowf[0][j][0] = ldb(j, 0, 0); rowf[0][j][1] = ldb(j, 0, 1); }
 #pragma unroll
         for (int dxp = 0; dxp < 7; ++dxp) {
-            bf8 prev[2] = {ldb(0, dxp, 0), ldb(0, dxp, 1)};
 #pragma unroll
             for (int dy = 0; dy < 13; ++dy) {
-                const bf8 a = __builtin_bit_cast(bf8, *(__attribute__((address_space(3))) const u32x4*)(uintptr_t)(abase + (unsigned)((dxp * 13 + dy) * 1024)));
-                const bf8 nx[2] = {ldb(dy + 1, dxp, 0), ldb(dy + 1, dxp, 1)};
+                if (dy == 0) {   // the column pair's remaining first rows (used by the LAST MFMAs of this tap row)
 #pragma unroll
-                for (int ct = 0; ct < 2; ++ct) {
-                    acc[0][ct] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, prev[ct], acc[0][ct], 0, 0, 0);
-                    acc[1][ct] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, nx[ct], acc[1][ct], 0, 0, 0);
+                    for (int j = PRE; j < RW; ++j) { rowf[dxp][j][0] = ldb(j, dxp, 0); rowf[dxp][j][1] = ldb(j, dxp, 1); }
                 }
-                prev[0] = nx[0];
-                prev[1] = nx[1];
+                if (dy < 12) {
+                    afr[dxp][dy + 1] = lda(dxp, dy + 1);
+                    rowf[dxp][dy + RW][0] = ldb(dy + RW, dxp, 0);
+                    rowf[dxp][dy + RW][1] = ldb(dy + RW, dxp, 1);
+                } else if (dxp < 6) {
+                    afr[dxp + 1][0] = lda(dxp + 1, 0);
+#pragma unroll
+                    for (int j = 0; j < PRE; ++j) { rowf[dxp + 1][j][0] = ldb(j, dxp + 1, 0); rowf[dxp + 1][j][1] = ldb(j, dxp + 1, 1); }
+                }
+#pragma unroll
+                for (int j = 0; j < RW; ++j)
+#pragma unroll
+                    for (int ct = 0; ct < 2; ++ct)
+                        acc[j][ct] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(afr[dxp][dy], rowf[dxp][dy + j][ct], acc[j][ct], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
             }
         }
-        // ---- store: lane holds channels 4g..4g+3 of pixel c16 of each of its four 16-pixel tiles ---------------------------
+        // ---- store: lane holds channels 4g..4g+3 of pixel c16 of each of its 2 RW 16-pixel tiles ---------------------------
 #pragma unroll
-        for (int pt = 0; pt < 2; ++pt)
+        for (int pt = 0; pt < RW; ++pt)
 #pragma unroll
             for (int ct = 0; ct < 2; ++ct) {
                 const int y = ty0 + r0 + pt, xx = tx0 + ct * 16 + c16;
@@ -125,13 +150,16 @@ extern "C" int hat_esc_conv13(const void* x, int32_t ldx, const void* wp, int32_
                               int32_t dtype, void* stream) {
     if (!x || !wp || !y16 || B < 1 || H < 1 || W < 1 || ldx < 16 || ldx % 8 || Kpad < 169 * 16 || Kpad % 8) return HAT_EINVAL;
     if (dtype != HAT_BF16) return HAT_EUNSUPPORTED;
-    auto kern = esc13_kernel;
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, E_LDS);
-    if (e != hipSuccess) return (int)e;
     const int tiles_x = (W + E_TC - 1) / E_TC, tiles_y = (H + E_TR - 1) / E_TR, ntiles = tiles_x * tiles_y;
     int gx = 256 / (B < 2 ? 1 : (B < 4 ? 2 : 4));
     if (gx > ntiles) gx = ntiles;
-    HAT_LAUNCH(kern, dim3(gx, B), dim3(E_WAVES * 64), E_LDS, reinterpret_cast<hipStream_t>(stream), reinterpret_cast<const bf16_t*>(x), ldx,
-               reinterpret_cast<const bf16_t*>(wp), Kpad, reinterpret_cast<bf16_t*>(y16), H, W, tiles_x, ntiles);
-    return hat_check_launch();
+    static const int rw = [] { const char* e = getenv("HAT_ESC13_RW"); return e && atoi(e) == 2 ? 2 : 4; }();   // 2: round 2's sixteen-wave shape (A/B)
+    auto launch = [&](auto kern, int waves) -> int {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, E_LDS);
+        if (e != hipSuccess) return (int)e;
+        HAT_LAUNCH(kern, dim3(gx, B), dim3(waves * 64), E_LDS, reinterpret_cast<hipStream_t>(stream), reinterpret_cast<const bf16_t*>(x), ldx,
+                   reinterpret_cast<const bf16_t*>(wp), Kpad, reinterpret_cast<bf16_t*>(y16), H, W, tiles_x, ntiles);
+        return hat_check_launch();
+    };
+    return rw == 2 ? launch(esc13_kernel<2>, 16) : launch(esc13_kernel<4>, 8);
 }

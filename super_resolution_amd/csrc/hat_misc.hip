@@ -130,12 +130,19 @@ __global__ __launch_bounds__(1024) void esc_weights_kernel(const float* __restri
         const int ci = tid & (gs - 1), pp = tid / gs;
         float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
         const float* gp = gap_partial + (size_t)b * nblk * gs + ci;
-        for (int k0 = pp; k0 < nblk; k0 += np * 8) {
-            float v[8];
+        // FOUR iterations' loads (32) are issued before the first add: a 720p frame has 7200 partial blocks = 15 iterations,
+        // each one round trip to wherever the tail's workgroups left them (other XCDs' L2 / HBM): 4 round trips instead of 15.
+        // The adds keep the order of the one-iteration-at-a-time loop (same bits).
+        for (int k0 = pp; k0 < nblk; k0 += np * 8 * 4) {
+            float v[4][8];
 #pragma unroll
-            for (int u = 0; u < 8; ++u) v[u] = gp[(size_t)min(k0 + np * u, nblk - 1) * gs];
+            for (int it = 0; it < 4; ++it)
 #pragma unroll
-            for (int u = 0; u < 8; ++u) acc[u] += (k0 + np * u < nblk) ? v[u] : 0.f;
+                for (int u = 0; u < 8; ++u) v[it][u] = gp[(size_t)min(k0 + np * (8 * it + u), nblk - 1) * gs];
+#pragma unroll
+            for (int it = 0; it < 4; ++it)
+#pragma unroll
+                for (int u = 0; u < 8; ++u) acc[u] += (k0 + np * (8 * it + u) < nblk) ? v[it][u] : 0.f;
         }
         part[pp * gs + ci] = ((acc[0] + acc[1]) + (acc[2] + acc[3])) + ((acc[4] + acc[5]) + (acc[6] + acc[7]));
     }
@@ -237,12 +244,15 @@ __global__ __launch_bounds__(256) void eca_scale_kernel(const float* __restrict_
 // DIRECT: few tiles — the workgroup sums the per-tile column sums itself (one launch instead of two)
 template <typename T, bool DIRECT>
 __global__ __launch_bounds__(256) void cab_fold_kernel(const HatCabFoldDesc d) {
-    __shared__ float red[256 * 33];  // [thread][4 lines x 8 channels], rows padded to 33 floats
-    __shared__ float part[8][32];
+    // 6.6 KB of LDS in all, so that the one workgroup fits on a CU beside a workgroup of the 13x13 ESC conv (155 KB of the CU's
+    // 160 KB, held for the conv's whole life) instead of waiting for one of them to exit.
+    __shared__ float sm[256 * 5 + 256];
+    float* red = sm;                                                    // [thread][4 values], rows padded to 5 floats: one of 8 passes
+    float (*part)[32] = reinterpret_cast<float (*)[32]>(sm + 256 * 5);   // [8][32]
+    float* mean = sm;                                                   // (after the sums are done)
+    float* scl = sm + 256;
     __shared__ float bord[4][8];     // first row, last row, first column, last column sums
     __shared__ float S[9][8];        // per-tap sums of c1 over the output pixels the tap contributes to
-    __shared__ float mean[256];
-    __shared__ float scl[256];
     const int tid = threadIdx.x, b = blockIdx.x;
     const int H = d.H, W = d.W, C = d.C, mid = d.mid;
     const T* c1 = reinterpret_cast<const T*>(d.c1) + (size_t)b * H * W * d.ld1;
@@ -258,30 +268,45 @@ __global__ __launch_bounds__(256) void cab_fold_kernel(const HatCabFoldDesc d) {
 #pragma unroll
             for (int c = 0; c < 8; ++c) a[line][c] = 0.f;
         const int lmax = W > H ? W : H;
-        for (int i = tid; i < lmax; i += 256) {
+        // BU iterations' loads (4 BU, clamped: unconditional) are in flight together: a load under a lane mask is waited for where
+        // it is issued, which made this loop 20 dependent round trips at 720p (40 of the kernel's 56 us; it is ONE workgroup, on
+        // the chain squeeze conv -> fold -> tail).  Additions in the order of the one-at-a-time loop.
+        constexpr int BU = sizeof(T) == 2 ? 5 : 2;
+        for (int i0 = tid; i0 < lmax; i0 += 256 * BU) {
+            typename MT<T>::frag_t v[BU][4];
 #pragma unroll
-            for (int line = 0; line < 4; ++line) {
-                const int len = line < 2 ? W : H;
-                if (i < len) {
+            for (int u = 0; u < BU; ++u)
+#pragma unroll
+                for (int line = 0; line < 4; ++line) {
+                    const int len = line < 2 ? W : H;
+                    const int i = min(i0 + u * 256, len - 1);
                     const size_t pix = line == 0 ? (size_t)i : line == 1 ? (size_t)(H - 1) * W + i : line == 2 ? (size_t)i * W : (size_t)i * W + (W - 1);
-                    const typename MT<T>::frag_t v = MT<T>::load(c1 + pix * d.ld1);
-#pragma unroll
-                    for (int c = 0; c < 8; ++c) a[line][c] += to_f(v[c]);
+                    v[u][line] = MT<T>::load(c1 + pix * d.ld1);
                 }
+#pragma unroll
+            for (int u = 0; u < BU; ++u)
+#pragma unroll
+                for (int line = 0; line < 4; ++line) {
+                    const bool in = i0 + u * 256 < (line < 2 ? W : H);
+#pragma unroll
+                    for (int c = 0; c < 8; ++c) a[line][c] += in ? to_f(v[u][line][c]) : 0.f;
+                }
+        }
+        // value v = line * 8 + channel: 32 interleaved partial sums of 32 threads each, then their sum — in eight passes of
+        // four values through the small staging buffer (same order of additions as one pass over all 32 values)
+#pragma unroll
+        for (int pass = 0; pass < 8; ++pass) {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) red[tid * 5 + k] = a[pass >> 1][(pass & 1) * 4 + k];
+            __syncthreads();
+            if (tid < 32) {
+                const int v4 = tid & 3, pt = tid >> 2;
+                float sp = 0.f;
+                for (int i = 0; i < 32; ++i) sp += red[(pt * 32 + i) * 5 + v4];
+                part[pt][pass * 4 + v4] = sp;
             }
+            __syncthreads();
         }
-#pragma unroll
-        for (int line = 0; line < 4; ++line)
-#pragma unroll
-            for (int c = 0; c < 8; ++c) red[tid * 33 + line * 8 + c] = a[line][c];
-        __syncthreads();
-        {
-            const int v = tid & 31, pt = tid >> 5;
-            float sp = 0.f;
-            for (int i = 0; i < 32; ++i) sp += red[(pt * 32 + i) * 33 + v];
-            part[pt][v] = sp;
-        }
-        __syncthreads();
         if (tid < 32) {
             float sp = 0.f;
             for (int i = 0; i < 8; ++i) sp += part[i][tid];
@@ -358,7 +383,7 @@ __global__ __launch_bounds__(256) void cab_fold_kernel(const HatCabFoldDesc d) {
     const int nt = (C + 15) / 16;
     for (int n = tid; n < nt * 16; n += 256) d.bias_out[(size_t)b * nt * 16 + n] = n < C ? d.bias_in[n] + scl[n] * d.b2[n] : 0.f;
     T* wf = reinterpret_cast<T*>(d.wf) + (size_t)b * nt * 3 * 512;
-    constexpr int FU = 9;  // elements per thread per batch
+    constexpr int FU = 18;  // elements per thread per batch (13 824 elements at C = 144: three batches)
     for (int i0 = tid; i0 < nt * 3 * 512; i0 += 256 * FU) {
         float wv[FU], bi[FU], b2v[FU];
         bool ok[FU];

@@ -34,6 +34,12 @@
 #ifndef T3_S0RD
 #define T3_S0RD 8           // stage 0: A-fragment read distance in MFMAs
 #endif
+#ifndef T3_ABL
+#define T3_ABL 0            // timing ablations for tools/ubench_tail3.hip (results wrong): 1 no weight copies in the chunk loop,
+#endif                      // 2 no U stores, 4 fc1 A fragments read once per chunk, 8 no MFMAs in phase A
+#ifndef T3_USTORE_IL
+#define T3_USTORE_IL 1      // 1: pair 0's U stores interleaved with pair 1's MFMAs (0: after them)
+#endif
 #ifndef T3_DMA_LATE
 #define T3_DMA_LATE 0       // 1: the next chunk's fc1 copies are issued after the barrier that ends phase A instead of at the chunk top
 #endif
@@ -304,23 +310,24 @@ __global__ __launch_bounds__(256, 2) void tail3_kernel(const HatFfnDesc d, const
     for (int chunk = 0; chunk < d.chunks; ++chunk) {
         // weights: fc2 + depthwise taps of THIS chunk (needed after the next barrier), fc1 of the next chunk (needed after the
         // barrier that ends this one).  Their buffers' last readers passed the barrier that ended the previous chunk.
-        dma_rest(chunk);
-        if constexpr (!T3_DMA_LATE) dma_fc1(min(chunk + 1, d.chunks - 1), (chunk + 1) & 1);
+        if constexpr (!(T3_ABL & 33)) dma_rest(chunk);
+        if constexpr (!T3_DMA_LATE && !(T3_ABL & 33)) dma_fc1(min(chunk + 1, d.chunks - 1), (chunk + 1) & 1);
         // ================================ phase A: fc1 -> Us (fp16) ====================================
         {
             const unsigned w1b = lds0 + T3_W1_OFF + (unsigned)((chunk & 1) * T3_W1_BYTES) + lane16;
-            f32x4 acc[2][2][3];
+            f32x4 acc[2][2][3] = {};
+            auto store_u1 = [&](int p, int t) {
+                u32x4 pk;
+#pragma unroll
+                for (int ii = 0; ii < 2; ++ii) {
+                    pk[2 * ii] = __builtin_bit_cast(unsigned, __builtin_amdgcn_cvt_pkrtz(acc[p][ii][t][0], acc[p][ii][t][1]));
+                    pk[2 * ii + 1] = __builtin_bit_cast(unsigned, __builtin_amdgcn_cvt_pkrtz(acc[p][ii][t][2], acc[p][ii][t][3]));
+                }
+                *(__attribute__((address_space(3))) u32x4*)(uintptr_t)(ust[t] + (unsigned)(p * 64)) = pk;
+            };
             auto store_u = [&](int p) {
 #pragma unroll
-                for (int t = 0; t < 3; ++t) {
-                    u32x4 pk;
-#pragma unroll
-                    for (int ii = 0; ii < 2; ++ii) {
-                        pk[2 * ii] = __builtin_bit_cast(unsigned, __builtin_amdgcn_cvt_pkrtz(acc[p][ii][t][0], acc[p][ii][t][1]));
-                        pk[2 * ii + 1] = __builtin_bit_cast(unsigned, __builtin_amdgcn_cvt_pkrtz(acc[p][ii][t][2], acc[p][ii][t][3]));
-                    }
-                    *(__attribute__((address_space(3))) u32x4*)(uintptr_t)(ust[t] + (unsigned)(p * 64)) = pk;
-                }
+                for (int t = 0; t < 3; ++t) store_u1(p, t);
             };
             // A fragments of step s = (pair p, k-step ks): two per step, requested T3_APF steps ahead of their MFMAs
             constexpr int APF = T3_APF, NSTEP = 2 * KS;
@@ -337,20 +344,28 @@ __global__ __launch_bounds__(256, 2) void tail3_kernel(const HatFfnDesc d, const
 #pragma unroll
                 for (int ks = 0; ks < KS; ++ks) {
                     const int step = p * KS + ks;
-                    if (step + APF < NSTEP) rd_a(step + APF);
+                    if (step + APF < NSTEP && !((T3_ABL & 4) && step + APF >= 1 + APF)) rd_a(step + APF);
+                    if constexpr (!(T3_ABL & 8))
 #pragma unroll
-                    for (int ii = 0; ii < 2; ++ii)
+                    for (int ii = 0; ii < 2; ++ii) {
 #pragma unroll
                         for (int t = 0; t < 3; ++t) {
                             const f32x4 c0 = ks == 0 ? f32x4{0.f, 0.f, 0.f, 0.f} : acc[p][ii][t];
                             acc[p][ii][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf8, ar[step % (APF + 1)][ii]), mb[t][ks], c0, 0, 0, 0);
                         }
+                        // pair 0's results leave (4 conversions + one 16-byte LDS store per pixel tile) in the shadow of pair 1's
+                        // MFMAs, one pixel tile per k-step: an MFMA holds the vector issue for half of its 16 cycles only
+                        if (T3_USTORE_IL && p == 1 && ii == 0 && ks >= 1 && ks <= 3 && !(T3_ABL & 18)) store_u1(0, ks - 1);
+                    }
                     __builtin_amdgcn_sched_barrier(0);
                 }
-                // the conversion + store of pair 0 is issued after the MFMAs of pair 1 were: their results are long complete
-                if (p == 1) store_u(0);
+                if (!T3_USTORE_IL && p == 1 && !(T3_ABL & 18)) store_u(0);
             }
-            store_u(1);
+            if constexpr (!(T3_ABL & 18)) store_u(1);
+            if constexpr ((T3_ABL & 16) != 0) {
+#pragma unroll
+                for (int q = 0; q < 12; ++q) asm volatile("" :: "v"(acc[q / 6][(q / 3) & 1][q % 3]));
+            }
         }
         stamp(2);
         // all but the 5 youngest copies (next chunk's fc1) have landed
@@ -359,6 +374,7 @@ __global__ __launch_bounds__(256, 2) void tail3_kernel(const HatFfnDesc d, const
         lds_barrier();     // Us, fc2 fragments and depthwise taps complete
         stamp(3);
         if constexpr (T3_DMA_LATE) dma_fc1(min(chunk + 1, d.chunks - 1), (chunk + 1) & 1);
+        if constexpr ((T3_ABL & 32) != 0) { dma_rest(chunk); dma_fc1(min(chunk + 1, d.chunks - 1), (chunk + 1) & 1); }
 
         // ====================== phase B: depthwise 3x3 in packed fp16 (this wave's two rows) ======================
         h2 da[2][4], dg[2][4];   // [tile row][dword]: a-units / gate-units 8g..8g+7, two per dword

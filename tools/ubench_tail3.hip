@@ -13,8 +13,10 @@ __global__ void fillb(bf16_t* p, size_t n, float s) { size_t i = blockIdx.x * (s
 __global__ void fillh(_Float16* p, size_t n, float s) { size_t i = blockIdx.x * (size_t)256 + threadIdx.x; if (i < n) p[i] = (_Float16)(s * (float)((i * 2654435761u) % 1000) / 1000.f - 0.5f * s); }
 
 static T3Aggr g_ag = {};
+static int g_lds = T3_LDS;     // > 81 920: one workgroup per CU (occupancy experiment)
 template <int DBG> float run(const HatFfnDesc& d, int iters) {
     auto kern = tail3_kernel<DBG>;
+    const int T3_LDS = g_lds;
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, T3_LDS);
     dim3 grid((d.W + 15) / 16, (d.H + 7) / 8, d.B);
     hipEvent_t a, b; (void)hipEventCreate(&a); (void)hipEventCreate(&b);
@@ -26,7 +28,9 @@ template <int DBG> float run(const HatFfnDesc& d, int iters) {
     return ms / iters;
 }
 
-int main() {
+int main(int argc, char** argv) {
+    if (argc > 1) g_lds = atoi(argv[1]);
+    printf("dynamic LDS %d B per workgroup\n", g_lds);
     const int H = 720, W = 1280, C = 144, chunks = 9;
     const size_t N = (size_t)H * W;
     float *tin, *tout, *vec; bf16_t *w1f, *nout; _Float16 *w2f, *dww;
