@@ -10,6 +10,7 @@
 // registers — the contraction index (key) ordering inside a 32-wide k-step is permuted
 // identically for both operands, so no LDS round trip or lane movement is needed for P.
 #include <cstdlib>
+#include <type_traits>
 
 #include "hat_common.h"
 
@@ -572,109 +573,149 @@ __global__ __launch_bounds__(NTH, WSE == 24 ? 2 : 4) void ocab_attn_fast_kernel(
         const int qt = wave + NWV * qi4;
         const size_t qpix = qpixel(qt, c16);
         frag_t qf = qfr[qi4];
-        float moff = 0.f;   // OFFS: the offset currently riding in the query fragment's channel 24 (log2 units, a bf16 value)
         // D = 24: lanes g == 3 meet a zero Q fragment and re-read group 2; D = 30: 4 slots per row, XOR-swizzled by the row
         const bf16_t* krow = (D == 24 && !OFFS) ? Ks + c16 * KR + (g < 3 ? 8 * g : 16) : Ks + c16 * KR + 8 * (g ^ ((c16 >> 1) & 3));
-        f32x4 o[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
-        float mrun = -3.0e38f;
-#pragma unroll 1
-        for (int ch = 0; ch < NKT / KCH; ++ch) {
-            const int kt0 = ch * KCH;
-            const float* tbase = tab + (CH_ROWS * ch - qt) * MR;
-            f32x4 s[KCH];
+        f32x4 o[2];
+        // OFFS: every LDS address of the (fully unrolled) chunk loop is a per-lane base plus an immediate; rolled up, 23 of the
+        // 76 vector instructions per 12 MFMAs were address additions.  The bias reads (four consecutive floats at a 4-byte-
+        // aligned address) get their per-lane bases once per query tile — 8 ch key rows further down the table is an
+        // immediate — and are `volatile`: left alone the load/store optimizer pairs them into ds_read2_b32, whose 8-bit
+        // offsets do not reach, and re-creates a base register with a v_add for every pair.
+        typedef const volatile __attribute__((address_space(3))) float* lds_vf_p;
+        lds_vf_p tq[KCH];
+        if constexpr (OFFS) {
 #pragma unroll
-            for (int t = 0; t < KCH; ++t) {
-                const float* tb = tbase + toff[t];
-                const f32x4 bias4 = {tb[0], tb[1], tb[2], tb[3]};
-                const frag_t kf = M::load(krow + (kt0 + t) * 16 * KR);
-                s[t] = M::mma(kf, qf, bias4);
-            }
-            if constexpr (SELF) {
-                // Shift mask (swinir_arch.py:262-280): bands [0, n-ws), [n-ws, n-shift), [n-shift, n) of the shifted frame,
-                // so only the last window row / column mixes bands.  Key tile t is key row kt0 + t, the query tile is
-                // query row qt (both wave-uniform); the lane's 4 key columns 4g.. share a band (shift % 4 == 0).
-                const bool lastr = wy == nwy - 1, lastc = wx == nwx - 1;
-                if (shift > 0 && (lastr || lastc)) {
-                    const float xm = (lastc && ((4 * g >= WS - shift) != (c16 >= WS - shift))) ? -100.0f : 0.0f;
+            for (int t = 0; t < KCH; ++t) tq[t] = (lds_vf_p)(__attribute__((address_space(3))) char*)reinterpret_cast<char*>(tab + toff[t] - qt * MR);
+        }
+        // One pass over the key window.  OFFS has two forms of it:
+        //   CHECKED = false (always tried first): the first chunk centres the offset on its row maximum and every later chunk
+        //     trusts it — no range check at all (it was 12 v_max3 |.| + a ballot per chunk, a sixth of the loop's VALU time).  A
+        //     later score far ABOVE the offset only makes p large (exp2 of up to ~100 is an ordinary float and bf16 has the same
+        //     exponent range); what cannot be represented shows in the denominator, and then
+        //   CHECKED = true: the pass is repeated with the range check and the re-centring step in every chunk (rare: it takes a
+        //     score 2^100 times the first chunk's maximum).
+        auto pass = [&](auto checked_tag) {
+            constexpr bool CHECKED = decltype(checked_tag)::value;
+            float moff = 0.f;   // OFFS: the offset currently riding in the query fragment's channel 24 (log2 units, a bf16 value)
+            if constexpr (OFFS) { if (g == 3) qf[0] = (bf16_t)0.f; }
+            o[0] = f32x4{0.f, 0.f, 0.f, 0.f};
+            o[1] = f32x4{0.f, 0.f, 0.f, 0.f};
+            float mrun = -3.0e38f;
+            constexpr int UNR = (OFFS && !CHECKED) ? NKT / KCH : 1;
+#pragma unroll UNR
+            for (int ch = 0; ch < NKT / KCH; ++ch) {
+                const int kt0 = ch * KCH;
+                const float* tbase = tab + (CH_ROWS * ch - qt) * MR;
+                f32x4 s[KCH];
 #pragma unroll
-                    for (int t = 0; t < KCH; ++t) {
-                        const bool ydiff = lastr && ((kt0 + t >= WS - shift) != (qt >= WS - shift));
-                        const float madd = ydiff ? -100.0f : xm;
-                        s[t][0] += madd; s[t][1] += madd; s[t][2] += madd; s[t][3] += madd;
+                for (int t = 0; t < KCH; ++t) {
+                    f32x4 bias4;
+                    if constexpr (OFFS && !CHECKED) {
+                        lds_vf_p tb = tq[t] + CH_ROWS * ch * MR;
+                        bias4 = f32x4{tb[0], tb[1], tb[2], tb[3]};
+                    } else {
+                        const float* tb = tbase + toff[t];
+                        bias4 = f32x4{tb[0], tb[1], tb[2], tb[3]};
+                    }
+                    const frag_t kf = M::load(krow + (kt0 + t) * 16 * KR);
+                    s[t] = M::mma(kf, qf, bias4);
+                }
+                if constexpr (SELF) {
+                    // Shift mask (swinir_arch.py:262-280): bands [0, n-ws), [n-ws, n-shift), [n-shift, n) of the shifted frame,
+                    // so only the last window row / column mixes bands.  Key tile t is key row kt0 + t, the query tile is
+                    // query row qt (both wave-uniform); the lane's 4 key columns 4g.. share a band (shift % 4 == 0).
+                    const bool lastr = wy == nwy - 1, lastc = wx == nwx - 1;
+                    if (shift > 0 && (lastr || lastc)) {
+                        const float xm = (lastc && ((4 * g >= WS - shift) != (c16 >= WS - shift))) ? -100.0f : 0.0f;
+#pragma unroll
+                        for (int t = 0; t < KCH; ++t) {
+                            const bool ydiff = lastr && ((kt0 + t >= WS - shift) != (qt >= WS - shift));
+                            const float madd = ydiff ? -100.0f : xm;
+                            s[t][0] += madd; s[t][1] += madd; s[t][2] += madd; s[t][3] += madd;
+                        }
                     }
                 }
-            }
-            float c2 = 0.f;      // exponent offset applied on the VALU (classic path only)
-            bool plain = true;   // (uniform) the offset the MFMA applied is good enough for this chunk
-            if constexpr (OFFS) {
-                float am = 0.f;
+                float c2 = 0.f;      // exponent offset applied on the VALU (classic path only)
+                if constexpr (OFFS) {
+                    bool plain = ch > 0;   // (uniform) the offset the MFMA applied is good enough for this chunk
+                    if constexpr (CHECKED) {
+                        float am = 0.f;
 #pragma unroll
-                for (int t = 0; t < KCH; ++t) am = max3_abs(max3_abs(am, s[t][0], s[t][1]), s[t][2], s[t][3]);
-                // The first chunk always centres on its row maximum (any sign: nothing is accumulated yet, and a row whose every
-                // logit lies far below zero must not underflow as a whole); later chunks re-centre only UPWARDS, when a score is
-                // more than 2^64 above the offset (a score far below it just contributes nothing).
-                plain = ch > 0 && __builtin_amdgcn_ballot_w64(am > 64.0f) == 0ull;
-                if (!plain) {
-                    asm volatile("; re-centre (rare path: keep it a branch, not predicated code)" ::: "memory");
+                        for (int t = 0; t < KCH; ++t) am = max3_abs(max3_abs(am, s[t][0], s[t][1]), s[t][2], s[t][3]);
+                        plain = ch > 0 && __builtin_amdgcn_ballot_w64(am > 64.0f) == 0ull;
+                    }
+                    // The first chunk always centres on its row maximum (any sign: nothing is accumulated yet, and a row whose every
+                    // logit lies far below zero must not underflow as a whole); later chunks (CHECKED) re-centre only UPWARDS, when
+                    // a score is more than 2^64 above the offset (a score far below it just contributes nothing).
+                    if (!plain) {
+                        float mx = -3.0e38f;
+#pragma unroll
+                        for (int t = 0; t < KCH; ++t) mx = max3_raw(max3_raw(mx, s[t][0], s[t][1]), s[t][2], s[t][3]);
+                        mx = fmaxf(mx, __shfl_xor(mx, 16));
+                        mx = fmaxf(mx, __shfl_xor(mx, 32));
+                        const float mnew = (float)(bf16_t)(moff + (ch == 0 ? mx : fmaxf(mx, 0.f)));   // what channel 24 can hold
+                        const float delta = mnew - moff;                           // (exact: both are short; >= 0 after the first chunk)
+                        if (ch > 0) {
+                            const float alpha = __builtin_amdgcn_exp2f(-delta);    // <= 1
+                            o[0] *= alpha;
+                            o[1] *= alpha;
+                        }
+#pragma unroll
+                        for (int t = 0; t < KCH; ++t) s[t] -= f32x4{delta, delta, delta, delta};
+                        moff = mnew;
+                        if (g == 3) qf[0] = (bf16_t)(-moff);
+                    }
+                } else {
                     float mx = -3.0e38f;
 #pragma unroll
                     for (int t = 0; t < KCH; ++t) mx = max3_raw(max3_raw(mx, s[t][0], s[t][1]), s[t][2], s[t][3]);
                     mx = fmaxf(mx, __shfl_xor(mx, 16));
                     mx = fmaxf(mx, __shfl_xor(mx, 32));
-                    const float mnew = (float)(bf16_t)(moff + (ch == 0 ? mx : fmaxf(mx, 0.f)));   // what channel 24 can hold
-                    const float delta = mnew - moff;                           // (exact: both are short; >= 0 after the first chunk)
-                    if (ch > 0) {
-                        const float alpha = __builtin_amdgcn_exp2f(-delta);    // <= 1
-                        o[0] *= alpha;
-                        o[1] *= alpha;
-                    }
-#pragma unroll
-                    for (int t = 0; t < KCH; ++t) s[t] -= f32x4{delta, delta, delta, delta};
-                    moff = mnew;
-                    if (g == 3) qf[0] = (bf16_t)(-moff);
+                    const float mnew = fmaxf(mrun, mx);
+                    const float alpha = __builtin_amdgcn_exp2f((mrun - mnew) * LOG2E);  // raw v_exp_f32: underflow flushes to 0
+                    mrun = mnew;
+                    c2 = -mnew * LOG2E;
+                    o[0] *= alpha;
+                    o[1] *= alpha;
                 }
-            } else {
-                float mx = -3.0e38f;
 #pragma unroll
-                for (int t = 0; t < KCH; ++t) mx = max3_raw(max3_raw(mx, s[t][0], s[t][1]), s[t][2], s[t][3]);
-                mx = fmaxf(mx, __shfl_xor(mx, 16));
-                mx = fmaxf(mx, __shfl_xor(mx, 32));
-                const float mnew = fmaxf(mrun, mx);
-                const float alpha = __builtin_amdgcn_exp2f((mrun - mnew) * LOG2E);  // raw v_exp_f32: underflow flushes to 0
-                mrun = mnew;
-                c2 = -mnew * LOG2E;
-                o[0] *= alpha;
-                o[1] *= alpha;
+                for (int kk = 0; kk < KCH / 2; ++kk) {
+                    frag_t pf;
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        if constexpr (OFFS) {
+                            pf[j] = (bf16_t)__builtin_amdgcn_exp2f(s[2 * kk][j]);
+                            pf[4 + j] = (bf16_t)__builtin_amdgcn_exp2f(s[2 * kk + 1][j]);
+                        } else {
+                            pf[j] = (bf16_t)__builtin_amdgcn_exp2f(fmaf(s[2 * kk][j], LOG2E, c2));
+                            pf[4 + j] = (bf16_t)__builtin_amdgcn_exp2f(fmaf(s[2 * kk + 1][j], LOG2E, c2));
+                        }
+                    }
+                    const int key0 = (kt0 + 2 * kk) * 16 + 4 * g;
+#pragma unroll
+                    for (int ct = 0; ct < 2; ++ct) {
+                        typedef short s16x4 __attribute__((ext_vector_type(4)));
+                        typedef s16x4 __attribute__((address_space(3))) * lds_s16x4_p;
+                        const bf16_t* va = Vs + (key0 + trq) * 32 + (ct ^ (g & 1)) * 16 + 4 * trp;
+                        const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_p)(va));
+                        const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_p)(va + 16 * 32));
+                        typedef short s16x8 __attribute__((ext_vector_type(8)));
+                        const s16x8 both = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+                        o[ct] = M::mma(__builtin_bit_cast(frag_t, both), pf, o[ct]);
+                    }
+                }
             }
-#pragma unroll
-            for (int kk = 0; kk < KCH / 2; ++kk) {
-                frag_t pf;
-#pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    if constexpr (OFFS) {
-                        pf[j] = (bf16_t)__builtin_amdgcn_exp2f(s[2 * kk][j]);
-                        pf[4 + j] = (bf16_t)__builtin_amdgcn_exp2f(s[2 * kk + 1][j]);
-                    } else {
-                        pf[j] = (bf16_t)__builtin_amdgcn_exp2f(fmaf(s[2 * kk][j], LOG2E, c2));
-                        pf[4 + j] = (bf16_t)__builtin_amdgcn_exp2f(fmaf(s[2 * kk + 1][j], LOG2E, c2));
-                    }
-                }
-                const int key0 = (kt0 + 2 * kk) * 16 + 4 * g;
-#pragma unroll
-                for (int ct = 0; ct < 2; ++ct) {
-                    typedef short s16x4 __attribute__((ext_vector_type(4)));
-                    typedef s16x4 __attribute__((address_space(3))) * lds_s16x4_p;
-                    const bf16_t* va = Vs + (key0 + trq) * 32 + (ct ^ (g & 1)) * 16 + 4 * trp;
-                    const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_p)(va));
-                    const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_p)(va + 16 * 32));
-                    typedef short s16x8 __attribute__((ext_vector_type(8)));
-                    const s16x8 both = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
-                    o[ct] = M::mma(__builtin_bit_cast(frag_t, both), pf, o[ct]);
-                }
+            // row ONE of O^T is the softmax denominator: register (ONE - 16) % 4 of lane group (ONE - 16) / 4, second tile
+            return __shfl(o[1][(ONE - 16) & 3], 16 * ((ONE - 16) >> 2) + c16);
+        };
+        float l = pass(std::false_type{});
+        if constexpr (OFFS) {
+            // (the query tile's 16 denominators: all finite and far from the top of the range, or the pass is repeated)
+            if (__builtin_amdgcn_ballot_w64(!(l < 1.0e30f)) != 0ull) {
+                asm volatile("; repeat the pass with range checks (rare path: keep it a branch)" ::: "memory");
+                l = pass(std::true_type{});
             }
         }
-        // row ONE of O^T is the softmax denominator: register (ONE - 16) % 4 of lane group (ONE - 16) / 4, second tile
-        const float l = __shfl(o[1][(ONE - 16) & 3], 16 * ((ONE - 16) >> 2) + c16);
         const float inv = 1.0f / l;
         bf16_t* op = out + qpix * ldo + h * D + 4 * g;
         if constexpr (D == 24) {

@@ -1104,12 +1104,14 @@ def test_hab_tail3_embed_dim_180(geom):
     check(gap.sum(1) / (H * W), n1[:, :, :16].float().mean(1), "f32", "hab tail 180 gap = pool of the stored rows", f32_tol=1e-5)
 
 
-@pytest.mark.parametrize("case", ["late_spike", "first_chunk_huge", "all_very_negative", "mixed"])
+@pytest.mark.parametrize("case", ["late_spike", "late_spike_overflow", "first_chunk_huge", "all_very_negative", "mixed"])
 def test_ocab_attention_fast_kernel_offset_range(case):
-    """The bf16 OCAB kernel of the embed_dim-144 models carries the softmax offset in a spare k-slot of the QK^T MFMA and only
-    re-centres when a chunk's scores leave +-64 (log2 units) around it.  Logits far outside that range — a spike in the last key
-    chunk, a first chunk hundreds above the rest, every logit far below zero, and all of it at once across windows — must take
-    the re-centring path and still match the fp64 softmax (hat_arch.py:375-384) at the bf16 bar."""
+    """The bf16 OCAB kernel of the embed_dim-144 models carries the softmax offset in a spare k-slot of the QK^T MFMA, centres
+    it on the first key chunk's row maximum and then runs the key window WITHOUT range checks; a query tile whose denominator
+    comes out non-finite or above 1e30 repeats its pass with a check and a re-centring step per chunk.  Logits far outside the
+    comfortable range — a spike in the last key chunk (~2^87 above the offset: still the unchecked pass; ~2^300 above it: exp2
+    overflows, the checked pass runs), a first chunk hundreds above the rest, every logit far below zero, and all of it at once
+    across windows — must still match the fp64 softmax (hat_arch.py:375-384) at the bf16 bar."""
     dev, ops = _dev(), _ops()
     ws, heads, C, H, W, B = 16, 6, 144, 32, 48, 1
     wse, d = 24, 24
@@ -1118,6 +1120,8 @@ def test_ocab_attention_fast_kernel_offset_range(case):
     table = rnd("otab", ((ws + wse - 1) ** 2, heads), std=0.5)
     if case in ("late_spike", "mixed"):
         kv[0, 19, 19, :C] *= 60.0          # bottom-right of window (0, 0)'s key window: its last key chunk
+    if case == "late_spike_overflow":
+        kv[0, 19, 19, :C] *= 200.0
     if case in ("first_chunk_huge", "mixed"):
         kv[0, 12:14, 16:40, :C] *= 45.0     # first key rows of the windows in window row 1
     if case == "all_very_negative":
