@@ -21,6 +21,10 @@
 bool hat_conv64r_can_launch(const HatConvDesc& d);
 int hat_conv64r_launch(const HatConvDesc& d, hipStream_t s);
 
+#ifndef HAT_CONV_PIPE
+#define HAT_CONV_PIPE 1   // 0: round 2's K loop (operand reads left to the scheduler), for A/B builds
+#endif
+
 namespace {
 
 struct TileCfg { int waves, pt; };
@@ -76,6 +80,18 @@ __global__ __launch_bounds__(WAVES * 64) void conv_kernel(const HatConvDesc d) {
 #endif
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6, g = lane >> 4, c16 = lane & 15;
+    if (d.reserved0 > 0) {
+        // One workgroup per CU and equal tiles: all 256 CUs would move through staging (HBM reads), K loop (no HBM traffic) and
+        // epilogue (HBM reads + writes) in lockstep, the memory system idle for half of every round and saturated for the
+        // rest.  The first round's workgroups start in four groups, d.reserved0 x 8128 cycles apart (hat_conv sets it: about a
+        // fifth of a tile time); later workgroups inherit the offsets because each starts when its CU's previous one ends.
+        // Group conv at 720p: 0.600 -> 0.580 ms.
+        const unsigned lin = (blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;
+        if (lin < 256u) {
+            const int n = (int)((lin >> 3) & 3u) * d.reserved0;
+            for (int i = 0; i < n; ++i) __builtin_amdgcn_s_sleep(127);
+        }
+    }
     const int ks_ = d.ksize;
     const int hl = ks_ >> 1, TWH = 16 + 2 * hl, THH = TROWS + 2 * hl;
     const int Cin = d.Cin, Cin_p = (Cin + 7) & ~7;
@@ -230,16 +246,44 @@ __global__ __launch_bounds__(WAVES * 64) void conv_kernel(const HatConvDesc d) {
             int ko[KS];
 #pragma unroll
             for (int ks = 0; ks < KS; ++ks) ko[ks] = koff[(chunk * KS + ks) * 4 + g];
+            if constexpr (HAT_CONV_PIPE && NT <= 9 && sizeof(T) == 2) {
+                // Weight fragments are requested AD n-tiles ahead of their MFMAs into a small register ring, the activation
+                // fragments of the next k-step while this one's last n-tiles run, and the scheduler may not move anything across
+                // an n-tile (sched_barrier).  Left to itself it allocates ONE register quad for the weight fragment and runs
+                // "read, wait, two MFMAs" nine times per k-step — the LDS latency nine times in the open, half the K loop's
+                // time in the 3x3 convs of the wide layers (group conv at 720p: 0.658 -> 0.606 ms; a ring of 2, 4, 5: 0.602,
+                // 0.614, 0.618 against 0.600 for 3 on one box).
+                constexpr int AD = 3, TOT = KS * NT;
+                typename M::frag_t af[AD + 1], bf[2][PT];
+                auto rd_a = [&](int i) { af[i % (AD + 1)] = M::load(Ws + ((i % NT) * 16 + c16) * ldws + (i / NT) * 32 + 8 * g); };
+                auto rd_b = [&](int ks) {
 #pragma unroll
-            for (int ks = 0; ks < KS; ++ks) {
-                typename M::frag_t bf[PT];
+                    for (int pt = 0; pt < PT; ++pt) bf[ks & 1][pt] = M::load(xrow + (size_t)pt * TWH * ldxs + ko[ks]);
+                };
+                rd_b(0);
 #pragma unroll
-                for (int pt = 0; pt < PT; ++pt) bf[pt] = M::load(xrow + (size_t)pt * TWH * ldxs + ko[ks]);
+                for (int i = 0; i < AD; ++i) rd_a(i);
 #pragma unroll
-                for (int nt = 0; nt < NT; ++nt) {
-                    const typename M::frag_t af = M::load(Ws + (nt * 16 + c16) * ldws + ks * 32 + 8 * g);
+                for (int i = 0; i < TOT; ++i) {
+                    const int ks = i / NT, nt = i % NT;
+                    if (i + AD < TOT) rd_a(i + AD);
+                    if (nt == (NT > AD ? NT - AD : 0) && ks + 1 < KS) rd_b(ks + 1);
 #pragma unroll
-                    for (int pt = 0; pt < PT; ++pt) acc[nt][pt] = M::mma(af, bf[pt], acc[nt][pt]);
+                    for (int pt = 0; pt < PT; ++pt) acc[nt][pt] = M::mma(af[i % (AD + 1)], bf[ks & 1][pt], acc[nt][pt]);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            } else {
+#pragma unroll
+                for (int ks = 0; ks < KS; ++ks) {
+                    typename M::frag_t bf[PT];
+#pragma unroll
+                    for (int pt = 0; pt < PT; ++pt) bf[pt] = M::load(xrow + (size_t)pt * TWH * ldxs + ko[ks]);
+#pragma unroll
+                    for (int nt = 0; nt < NT; ++nt) {
+                        const typename M::frag_t af = M::load(Ws + (nt * 16 + c16) * ldws + ks * 32 + 8 * g);
+#pragma unroll
+                        for (int pt = 0; pt < PT; ++pt) acc[nt][pt] = M::mma(af, bf[pt], acc[nt][pt]);
+                    }
                 }
             }
         };
@@ -438,7 +482,11 @@ int launch_conv(const HatConvDesc& d, size_t lds, hipStream_t stream) {
         if (e != hipSuccess) return (int)e;
     }
     dim3 grid((d.W + 15) / 16, (d.H + WAVES * PT - 1) / (WAVES * PT), d.B);
-    HAT_LAUNCH(kern, grid, dim3(WAVES * 64), lds, stream, d);
+    HatConvDesc dd = d;
+    // stagger (kernel side: see conv_kernel): only for launches that keep every CU busy for several rounds of ONE workgroup each
+    static const int stag = [] { const char* e = getenv("HAT_CONV_STAGGER"); return e ? atoi(e) : 2; }();
+    dd.reserved0 = (lds > HAT_LDS_MAX / 2 && (size_t)grid.x * grid.y * grid.z >= 1024) ? stag : 0;
+    HAT_LAUNCH(kern, grid, dim3(WAVES * 64), lds, stream, dd);
     return hat_check_launch();
 }
 
