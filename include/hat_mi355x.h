@@ -303,9 +303,11 @@ int hat_ocab_attention(const void* q, const void* kv, const float* bias_rot, voi
  * hat_ocab_attention for the tuned kernel of the embed_dim-144 models (bf16, 16 x 16 windows, 24 x 24 key windows, head_dim 24;
  * HAT_EUNSUPPORTED otherwise), with q ALREADY multiplied by head_dim^-1/2 * log2(e) — the caller folds the factor into the q
  * projection's weights before they are rounded, so the scores are in log2 units at no extra rounding.  The kernel then carries
- * the softmax's running offset in a spare k-slot of the QK^T MFMA (K rows hold 1.0, the query fragment -offset): p = exp2(score)
- * with no per-score FMA and no rescale of O while every score of a 96-key chunk stays within 2^+-64 of the offset; a chunk
- * that leaves the range re-centres the classic way.  Same result as hat_ocab_attention up to rounding (hat_arch.py:375-384).
+ * the softmax's offset in a spare k-slot of the QK^T MFMA (K rows hold 1.0, the query fragment -offset): p = exp2(score) with no
+ * per-score FMA and no rescale of O.  The offset is the row maximum of the first 96-key chunk; the rest of the key window runs
+ * without range checks, and a query tile whose softmax denominator comes out non-finite or above 1e30 (a later score more than
+ * ~2^100 above the first chunk's maximum) is computed again with a check and a re-centring step per chunk.  Same result as
+ * hat_ocab_attention up to rounding (hat_arch.py:375-384).
  */
 int hat_ocab_attention_log2(const void* q, const void* kv, const float* bias_rot, void* out, int32_t B, int32_t H, int32_t W,
                             int32_t C, int32_t heads, int32_t ws, int32_t wse, int32_t ldq, int32_t ldkv, int32_t ldo,
@@ -313,9 +315,10 @@ int hat_ocab_attention_log2(const void* q, const void* kv, const float* bias_rot
 
 /*
  * CAB squeeze conv: GELU_erf(conv3x3(x, C -> mid <= 8 channels, zero pad) + bias)   (hat_arch.py:84-85, cab.0 + GELU)
- * for bf16 rows without LDS operand traffic: a wave sweeps a 16-pixel-wide strip of rows, activations come straight from
- * global memory, the weights stay in registers, and the three taps of a kernel column are routed to three rolling
- * output-row accumulators by the choice of MFMA C operand (csrc/hat_cabsq.hip).
+ * for bf16 rows without LDS operand traffic: a wave sweeps a strip of 14 output columns (16 loaded ones: a halo column on each
+ * side) top to bottom, every input row's activations come straight from global memory ONCE (the fragments of the two
+ * horizontally shifted taps are lane shifts of the loaded one), the weights stay in registers, and the three taps of a
+ * kernel column are routed to three rolling output-row accumulators by the choice of MFMA C operand (csrc/hat_cabsq.hip).
  * x: (B,H,W,ldx) bf16, 128 < C <= 160, C % 8 == 0; W % 16 == 0.
  * wpk: 6 tiles x 5 k-steps of MFMA A fragments [tile][kstep][64 lanes][8] bf16, tile = 2*kx + j:
  *      j = 0: rows 0-7 = w[ch][.][ky=0][kx], rows 8-15 = w[ch][.][ky=1][kx];  j = 1: rows 0-7 = w[ch][.][ky=2][kx], rest 0

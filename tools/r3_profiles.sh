@@ -7,7 +7,7 @@ R=$(pwd); O=$R/gpurun_out; export TMPDIR=/tmp
 tools/profile_round.sh r03_final > $O/r03_profile_round.log 2>&1 || { tail -5 $O/r03_profile_round.log; exit 1; }
 echo "standard set done"
 cd /tmp
-for arm in v3 v2; do
+for arm in ${SKIP_L2:+} $( [ -z "$SKIP_L2" ] && echo v3 v2 ); do
   rm -rf $O/pmcL_$arm
   if [ $arm = v2 ]; then export HAT_TAIL_V2=1; else unset HAT_TAIL_V2; fi
   ( cd $R && timeout -k 10 400 rocprofv3 --pmc TCP_TCC_READ_REQ_sum TCC_REQ_sum TCC_HIT_sum TCC_MISS_sum --output-format csv -d $O/pmcL_$arm -- python3 tools/run_forward.py > $O/pmcL_$arm.log 2>&1 ) || { tail -5 $O/pmcL_$arm.log; exit 1; }
