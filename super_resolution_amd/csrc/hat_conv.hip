@@ -46,7 +46,9 @@ __host__ inline bool conv_pick(const HatConvDesc& d, TileCfg* out, size_t* lds) 
     // workgroup's load / store phases overlap the other's MFMA phase — only when the weight slice is cheap to
     // re-stream per tile (smaller tiles re-read it more often); otherwise the largest tile that fits
     const size_t wbytes = (size_t)d.nt * 16 * d.ksize * d.ksize * ((d.Cin + 7) & ~7) * es;
-    for (int pass = (wbytes <= 65536 ? 0 : 1); pass < 2; ++pass) {
+    // (measured at 720p: 144 -> 64, 166 KB of weights, 0.278 ms with one 16-row tile per CU and 0.232 with two 8-row tiles;
+    // 144 -> 144, 373 KB: 0.58 against 0.98)
+    for (int pass = (wbytes <= 180000 ? 0 : 1); pass < 2; ++pass) {
         const size_t limit = pass == 0 ? HAT_LDS_MAX / 2 : HAT_LDS_MAX;
         for (int i = 0; i < 3; ++i) {
             const int rows = cands[i].waves * cands[i].pt;
@@ -130,30 +132,34 @@ __global__ __launch_bounds__(WAVES * 64) void conv_kernel(const HatConvDesc d) {
         // under a lane mask is waited for where it is issued, which made this loop one memory round trip per piece
         // (13 in flight when the tile needs more than 6 per thread: the CAB squeeze conv's tile is 13 pieces per thread and
         // its K loop is short, so each extra round trip of staging showed directly in its time)
+        // piece i = (haloed pixel q = (qy, qx), 16-byte piece r of its row): a thread's pieces are NTHR apart, so (q, r) and
+        // (qy, qx) advance by fixed amounts with a carry — four integer divisions per thread in all.  (Two divisions by run-time
+        // divisors per piece, done again for the store, were ~2 000 vector instructions per thread: more than half of this phase.)
+        const int dq = NTHR / ppp, dr = NTHR - dq * ppp, dqy = dq / TWH, dqx = dq - dqy * TWH;
         auto stage = [&](auto su_tag) {
             constexpr int SU = decltype(su_tag)::value;
+            int q = tid / ppp, r = tid - q * ppp;
+            int qy = q / TWH, qx = q - qy * TWH;
             for (int i0 = tid; i0 < total; i0 += NTHR * SU) {
                 u32x4 v[SU];
                 bool ok[SU];
+                int lo[SU];
 #pragma unroll
                 for (int u = 0; u < SU; ++u) {
-                    const int i = min(i0 + u * NTHR, total - 1);
-                    const int q = i / ppp, c = (i - q * ppp) * VEC;
-                    const int qy = q / TWH, qx = q - qy * TWH;
+                    const int c = r * VEC;
                     const int y = y0 - hl + qy, x = x0 - hl + qx;
                     ok[u] = y >= 0 && y < H && x >= 0 && x < W && c < Cin;
+                    lo[u] = q * ldxs + c;
                     const size_t pix = ((size_t)b * H + min(max(y, 0), H - 1)) * W + min(max(x, 0), W - 1);
                     const T* src = (xg0 != nullptr && c < d.c_split) ? xg0 + pix * d.ldx0 + c : xg + pix * d.ldx + c;
-                    v[u] = *reinterpret_cast<const u32x4*>(src);
+                    v[u] = *reinterpret_cast<const u32x4*>(src);   // (pieces past the tile re-read a clamped pixel: never stored)
+                    r += dr; q += dq; qx += dqx; qy += dqy;
+                    if (r >= ppp) { r -= ppp; q += 1; qx += 1; }
+                    if (qx >= TWH) { qx -= TWH; qy += 1; }
                 }
 #pragma unroll
-                for (int u = 0; u < SU; ++u) {
-                    const int i = i0 + u * NTHR;
-                    if (i < total) {
-                        const int q = i / ppp, c = (i - q * ppp) * VEC;
-                        *reinterpret_cast<u32x4*>(Xs + (size_t)q * ldxs + c) = ok[u] ? v[u] : u32x4{0u, 0u, 0u, 0u};
-                    }
-                }
+                for (int u = 0; u < SU; ++u)
+                    if (i0 + u * NTHR < total) *reinterpret_cast<u32x4*>(Xs + lo[u]) = ok[u] ? v[u] : u32x4{0u, 0u, 0u, 0u};
             }
         };
         if (total > NTHR * 6) stage(std::integral_constant<int, 13>{});
@@ -309,13 +315,59 @@ __global__ __launch_bounds__(WAVES * 64) void conv_kernel(const HatConvDesc d) {
         const long long st2 = (long long)__builtin_amdgcn_s_memtime();
 #endif
         // ---------------------------------- epilogue ------------------------------------------
-        // n-tiles are finished in groups of NG: the group's residual operands (r1, r2, r2's scale) are loaded in ONE
-        // batch before any of its stores — `out` may alias r1 (in-place residual), so loads placed between the stores
-        // are serialised one memory round trip at a time.
         const int nbase = slice * NT * 16;
         const bool want_cs = d.colsum != nullptr;
         constexpr int NG = NT % 3 == 0 ? 3 : (NT % 2 == 0 ? 2 : 1);
         const bool has_r1 = d.r1 != nullptr, has_r2 = d.r2 != nullptr;
+        // bf16 layers: Pass A — every load of the epilogue, no store: bias, activation and the residual terms go into the
+        // accumulators group by group.  Pass B — the stores.  vmcnt counts loads and stores in issue order, so a load issued after
+        // stores is waited for together with every one of those stores' acknowledgements; interleaved (round 2, and still the
+        // fp32 instantiations, whose registers do not allow the split) that happens four to five times per tile — each later
+        // residual batch behind the previous batch's stores, the LayerNorm's gamma / beta behind the fp32 stores of each pixel
+        // row.  The LayerNorm parameters of the fused form come from an LDS table (behind the column-sum scratch in the weight
+        // chunk's buffer, which every wave is done with), filled here.
+        constexpr bool TWO_PASS = sizeof(T) == 2;
+        float* lnt = cs + 2048;
+        float lpg = 0.f, lpb = 0.f;
+        const bool ln_tab = TWO_PASS && NT >= 8 && NT * 16 <= NTHR && d.ln_out != nullptr;
+        if (ln_tab && tid < NT * 16) { lpg = d.ln_g[tid]; lpb = d.ln_b[tid]; }
+        // store of one finished (n-tile, pixel row) by out_mode
+        auto put = [&](int nt, int pt, const f32x4& v, f32x4& csum) {
+            const int n = nbase + nt * 16 + 4 * g;  // first of this lane's 4 consecutive channels
+            const int y = y0 + wave * PT + pt, x = x0 + c16;
+            const bool valid = (y < H) && (x < W);
+            if (valid && n < d.n_store) {
+                const size_t pix = ((size_t)b * H + y) * W + x;
+                if (d.out_mode == HAT_O_NHWC_T) {
+                    Vec4<T>::store(reinterpret_cast<T*>(d.out) + pix * d.ldo + n, v);
+                } else if (d.out_mode == HAT_O_NHWC_F32) {
+                    *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(d.out) + pix * d.ldo + n) = v;
+                } else if (d.out_mode == HAT_O_PIXSHUF_T) {
+                    const int r_ = d.ps_r, cps = d.n_store / (r_ * r_);
+                    const int ij = n / cps, cc = n - ij * cps;
+                    const int i_ = ij / r_, j_ = ij - i_ * r_;
+                    const size_t opix = ((size_t)b * H * r_ + (size_t)y * r_ + i_) * ((size_t)W * r_) + (size_t)x * r_ + j_;
+                    Vec4<T>::store(reinterpret_cast<T*>(d.out) + opix * d.ldo + cc, v);
+                } else {  // HAT_O_NCHW_F32
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+                        if (n + r < d.n_store)
+                            reinterpret_cast<float*>(d.out)[(((size_t)b * d.n_store + n + r) * H + y) * W + x] =
+                                v[r] * d.out_scale + d.mean[(n + r) & 3];
+                }
+            }
+            if (want_cs && valid) csum += d.out_mode == HAT_O_NHWC_T ? as_stored<T>(v) : v;   // (the pool of the STORED map)
+        };
+        auto put_cs = [&](int nt, const f32x4& csum) {
+            if (want_cs) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    float s = csum[r];
+                    s = row_sum16(s);
+                    if (c16 == 0) cs[wave * (NT * 16) + nt * 16 + 4 * g + r] = s;
+                }
+            }
+        };
 #pragma unroll
         for (int ng = 0; ng < NT; ng += NG) {
             f32x4 r1v[NG][PT], scv[NG], biasv[NG];
@@ -336,12 +388,9 @@ __global__ __launch_bounds__(WAVES * 64) void conv_kernel(const HatConvDesc d) {
 #pragma unroll
             for (int i = 0; i < NG; ++i) {
                 const int nt = ng + i;
-                const int n = nbase + nt * 16 + 4 * g;  // first of this lane's 4 consecutive channels
                 f32x4 csum = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
                 for (int pt = 0; pt < PT; ++pt) {
-                    const int y = y0 + wave * PT + pt, x = x0 + c16;
-                    const bool valid = (y < H) && (x < W);
                     f32x4 v = acc[nt][pt] + biasv[i];
                     if (d.act == HAT_ACT_GELU) {
 #pragma unroll
@@ -352,37 +401,23 @@ __global__ __launch_bounds__(WAVES * 64) void conv_kernel(const HatConvDesc d) {
                     }
                     if (has_r1) v += r1v[i][pt];
                     if (has_r2) v += scv[i] * Vec4<T>::cvt(r2v[i][pt]);
-                    acc[nt][pt] = v;   // (the fused LayerNorm below needs the finished pixel)
-                    if (valid && n < d.n_store) {
-                        const size_t pix = ((size_t)b * H + y) * W + x;
-                        if (d.out_mode == HAT_O_NHWC_T) {
-                            Vec4<T>::store(reinterpret_cast<T*>(d.out) + pix * d.ldo + n, v);
-                        } else if (d.out_mode == HAT_O_NHWC_F32) {
-                            *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(d.out) + pix * d.ldo + n) = v;
-                        } else if (d.out_mode == HAT_O_PIXSHUF_T) {
-                            const int r_ = d.ps_r, cps = d.n_store / (r_ * r_);
-                            const int ij = n / cps, cc = n - ij * cps;
-                            const int i_ = ij / r_, j_ = ij - i_ * r_;
-                            const size_t opix = ((size_t)b * H * r_ + (size_t)y * r_ + i_) * ((size_t)W * r_) + (size_t)x * r_ + j_;
-                            Vec4<T>::store(reinterpret_cast<T*>(d.out) + opix * d.ldo + cc, v);
-                        } else {  // HAT_O_NCHW_F32
-#pragma unroll
-                            for (int r = 0; r < 4; ++r)
-                                if (n + r < d.n_store)
-                                    reinterpret_cast<float*>(d.out)[(((size_t)b * d.n_store + n + r) * H + y) * W + x] =
-                                        v[r] * d.out_scale + d.mean[(n + r) & 3];
-                        }
-                    }
-                    if (want_cs && valid) csum += d.out_mode == HAT_O_NHWC_T ? as_stored<T>(v) : v;   // (the pool of the STORED map)
+                    acc[nt][pt] = v;   // (pass B and the fused LayerNorm below need the finished pixel)
+                    if constexpr (!TWO_PASS) put(nt, pt, v, csum);
                 }
-                if (want_cs) {
+                if constexpr (!TWO_PASS) put_cs(nt, csum);
+            }
+        }
+        if (ln_tab) {
+            if (tid < NT * 16) { lnt[tid] = lpg; lnt[NT * 16 + tid] = lpb; }
+            lds_barrier();
+        }
+        if constexpr (TWO_PASS) {
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        float s = csum[r];
-                        s = row_sum16(s);
-                        if (c16 == 0) cs[wave * (NT * 16) + nt * 16 + 4 * g + r] = s;
-                    }
-                }
+            for (int nt = 0; nt < NT; ++nt) {
+                f32x4 csum = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int pt = 0; pt < PT; ++pt) put(nt, pt, acc[nt][pt], csum);
+                put_cs(nt, csum);
             }
         }
         if (d.ln_out != nullptr) {
@@ -411,8 +446,8 @@ __global__ __launch_bounds__(WAVES * 64) void conv_kernel(const HatConvDesc d) {
 #pragma unroll
                 for (int nt = 0; nt < NT; ++nt) {
                     const int n = nt * 16 + 4 * g;
-                    const f32x4 gm = *reinterpret_cast<const f32x4*>(d.ln_g + n);
-                    const f32x4 bt = *reinterpret_cast<const f32x4*>(d.ln_b + n);
+                    const f32x4 gm = ln_tab ? *reinterpret_cast<const f32x4*>(lnt + n) : *reinterpret_cast<const f32x4*>(d.ln_g + n);
+                    const f32x4 bt = ln_tab ? *reinterpret_cast<const f32x4*>(lnt + NT * 16 + n) : *reinterpret_cast<const f32x4*>(d.ln_b + n);
                     f32x4 o;
 #pragma unroll
                     for (int r = 0; r < 4; ++r) o[r] = (acc[nt][pt][r] - mean) * rstd * gm[r] + bt[r];
