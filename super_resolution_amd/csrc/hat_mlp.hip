@@ -90,43 +90,67 @@ __global__ __launch_bounds__(WAVES * 64) void ocab_mlp_kernel(const HatMlpDesc d
         asm volatile("" : "+v"(wofs));
         const char* wl = smem + wofs;
         const char* wl8 = smem + ML_OFF_W1H + (wofs >> 1);   // the half fragments: 8 bytes per lane
+        // Weight fragments are requested ahead of their MFMAs into their own registers — fc1: the five fragments + bias of channel
+        // tile nt + 1 while tile nt's five MFMAs run; fc2: a four-deep ring, three fragments ahead — and the scheduler may not move
+        // anything across a step (sched_barrier).  Left to itself it reads each fragment right before its MFMA and drains the LDS
+        // queue (s_waitcnt lgkmcnt(0)) 140 times for the 171 MFMAs of a tile: the kernel ran at the pace of that chain, 0.33 ms,
+        // not of its 1.06 GB (hat_conv.hip's K loop had the same disease).
         // ---- fc1 + GELU -> the B fragments of fc2 -------------------------------------------------------------------------
         frag_t pf[ML_KK];
+        {
+            struct W1 { s16x4 h; f32x4 b; frag_t f[4]; };
+            W1 ws[2];
+            auto rd1 = [&](int nt, W1& w) {
+                w.h = *reinterpret_cast<const s16x4*>(wl8 + nt * 512);
+                w.b = *reinterpret_cast<const f32x4*>(b1l + nt * 16 + 4 * g);
 #pragma unroll
-        for (int kk = 0; kk < ML_KK; ++kk) {
+                for (int ks = 0; ks < 4; ++ks) w.f[ks] = *reinterpret_cast<const frag_t*>(wl + (nt * 4 + ks) * 1024);
+            };
+            rd1(0, ws[0]);
             f32x4 a[2];
 #pragma unroll
-            for (int i = 0; i < 2; ++i) {
-                const int nt = 2 * kk + i;
+            for (int nt = 0; nt < ML_NT1; ++nt) {
+                if (nt + 1 < ML_NT1) rd1(nt + 1, ws[(nt + 1) & 1]);
+                const W1& w = ws[nt & 1];
                 // The 16-deep tail accumulates SEPARATELY (bias as its C operand) and is added on the VALU: chained behind the
                 // fourth 16x16x32 MFMA as its C operand, the 16x16x16 MFMA read the accumulator before that result had landed
                 // (the k-step 3 contribution was lost: hipcc places no wait states between the two MFMA shapes on gfx950).
-                const s16x4 wh = *reinterpret_cast<const s16x4*>(wl8 + nt * 512);
-                const f32x4 tail = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(wh, xcur.h, *reinterpret_cast<const f32x4*>(b1l + nt * 16 + 4 * g), 0, 0, 0);
-                a[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+                const f32x4 tail = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(w.h, xcur.h, w.b, 0, 0, 0);
+                f32x4 ai = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-                for (int ks = 0; ks < 4; ++ks)
-                    a[i] = M::mma(*reinterpret_cast<const frag_t*>(wl + (nt * 4 + ks) * 1024), xcur.f[ks], a[i]);
-                a[i] += tail;
-            }
+                for (int ks = 0; ks < 4; ++ks) ai = M::mma(w.f[ks], xcur.f[ks], ai);
+                a[nt & 1] = ai + tail;
+                if (nt & 1) {
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                pf[kk][j] = (bf16_t)gelu_act<T>(a[0][j]);
-                pf[kk][4 + j] = (bf16_t)gelu_act<T>(a[1][j]);
+                    for (int j = 0; j < 4; ++j) {
+                        pf[nt >> 1][j] = (bf16_t)gelu_act<T>(a[0][j]);
+                        pf[nt >> 1][4 + j] = (bf16_t)gelu_act<T>(a[1][j]);
+                    }
+                }
+                __builtin_amdgcn_sched_barrier(0);
             }
         }
         // ---- fc2 + bias + residual ----------------------------------------------------------------------------------------
         f32x4 acc[ML_NT2];
+        {
+            constexpr int NF = ML_NT2 * ML_KK - ML_NREG, AD = 3;   // fragments that live in LDS; ring depth
+            frag_t ring[AD + 1];
+            auto rd2 = [&](int f) { ring[f % (AD + 1)] = *reinterpret_cast<const frag_t*>(wl + ML_OFF_W2 + f * 1024); };
 #pragma unroll
-        for (int nt = 0; nt < ML_NT2; ++nt) {
-            acc[nt] = *reinterpret_cast<const f32x4*>(b2l + nt * 16 + 4 * g) + r1v[nt];
+            for (int f = 0; f < AD; ++f) rd2(f);
 #pragma unroll
-            for (int kk = 0; kk < ML_KK; ++kk) {
-                const int f = nt * ML_KK + kk;
-                if (f < ML_NT2 * ML_KK - ML_NREG)
-                    acc[nt] = M::mma(*reinterpret_cast<const frag_t*>(wl + ML_OFF_W2 + f * 1024), pf[kk], acc[nt]);
-                else
-                    acc[nt] = M::mma(w2r[f - (ML_NT2 * ML_KK - ML_NREG)], pf[kk], acc[nt]);
+            for (int nt = 0; nt < ML_NT2; ++nt) {
+                acc[nt] = *reinterpret_cast<const f32x4*>(b2l + nt * 16 + 4 * g) + r1v[nt];
+#pragma unroll
+                for (int kk = 0; kk < ML_KK; ++kk) {
+                    const int f = nt * ML_KK + kk;
+                    if (f + AD < NF) rd2(f + AD);
+                    if (f < NF)
+                        acc[nt] = M::mma(ring[f % (AD + 1)], pf[kk], acc[nt]);
+                    else
+                        acc[nt] = M::mma(w2r[f - NF], pf[kk], acc[nt]);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
             }
         }
         // the next tile's operands have arrived; rotate, then store (every lane stores: lanes past the last pixel re-store it)
@@ -197,27 +221,32 @@ __global__ __launch_bounds__(WAVES * 64) void ocab_qkv_kernel(const HatMlpDesc d
         const char* wl = smem + wofs;
         const char* wl8 = smem + QK_WF + (wofs >> 1);
         bf16_t* o = reinterpret_cast<bf16_t*>(d.out) + pc * d.ldo;
-        // channel tiles in pairs: results leave as 16-byte stores while the next pair's MFMAs run
+        // channel tiles in pairs: results leave as 16-byte stores while the next pair's MFMAs run.  The five weight fragments +
+        // bias of channel tile nt + 1 are requested while tile nt's five MFMAs run, order pinned (see ocab_mlp_kernel).
         f32x4 last = {0.f, 0.f, 0.f, 0.f};
+        struct W1 { s16x4 h; f32x4 b; frag_t f[4]; };
+        W1 ws[2];
+        auto rd1 = [&](int nt, W1& w) {
+            w.h = *reinterpret_cast<const s16x4*>(wl8 + nt * 512);
+            w.b = *reinterpret_cast<const f32x4*>(bl + nt * 16 + 4 * g);
 #pragma unroll
-        for (int np = 0; np < (QK_NT + 1) / 2; ++np) {
-            f32x4 a[2];
+            for (int ks = 0; ks < 4; ++ks) w.f[ks] = *reinterpret_cast<const frag_t*>(wl + (nt * 4 + ks) * 1024);
+        };
+        rd1(0, ws[0]);
+        f32x4 a[2];
 #pragma unroll
-            for (int i = 0; i < 2; ++i) {
-                const int nt = 2 * np + i;
-                if (nt < QK_NT) {
-                    // (the 16-deep tail accumulates separately: see ocab_mlp_kernel)
-                    const s16x4 wh = *reinterpret_cast<const s16x4*>(wl8 + nt * 512);
-                    const f32x4 tail = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(wh, xcur.h, *reinterpret_cast<const f32x4*>(bl + nt * 16 + 4 * g), 0, 0, 0);
-                    a[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int nt = 0; nt < QK_NT; ++nt) {
+            if (nt + 1 < QK_NT) rd1(nt + 1, ws[(nt + 1) & 1]);
+            const W1& w = ws[nt & 1];
+            // (the 16-deep tail accumulates separately: see ocab_mlp_kernel)
+            const f32x4 tail = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(w.h, xcur.h, w.b, 0, 0, 0);
+            f32x4 ai = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-                    for (int ks = 0; ks < 4; ++ks)
-                        a[i] = M::mma(*reinterpret_cast<const frag_t*>(wl + (nt * 4 + ks) * 1024), xcur.f[ks], a[i]);
-                    a[i] += tail;
-                }
-            }
-            if (2 * np + 1 < QK_NT) store_pair_bf16(o, 2 * np * 16, g, a[0], a[1]);
-            else last = a[0];
+            for (int ks = 0; ks < 4; ++ks) ai = M::mma(w.f[ks], xcur.f[ks], ai);
+            a[nt & 1] = ai + tail;
+            if (nt & 1) store_pair_bf16(o, (nt - 1) * 16, g, a[0], a[1]);
+            else if (nt == QK_NT - 1) last = a[0];
+            __builtin_amdgcn_sched_barrier(0);
         }
         Vec4<T>::store(o + (QK_NT - 1) * 16 + 4 * g, last);
         xcur = xnxt;
