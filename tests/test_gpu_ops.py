@@ -857,11 +857,14 @@ def test_window_attention_rejects_bad_arguments():
 # ------------------------------------------------------------------------------------------------
 # CAB squeeze conv on the row-sweep kernel (hat_cab_squeeze)
 # ------------------------------------------------------------------------------------------------
-@pytest.mark.parametrize("geom", [(1, 48, 64, 144, 6), (2, 21, 32, 144, 6), (1, 8, 16, 136, 8), (1, 100, 48, 160, 3)],
-                         ids=["48x64", "B2_21x32_ragged_rows", "one_band_C136_mid8", "C160_mid3"])
+@pytest.mark.parametrize("geom", [(1, 48, 64, 144, 6), (2, 21, 32, 144, 6), (1, 8, 16, 136, 8), (1, 100, 48, 160, 3), (1, 9, 112, 144, 6),
+                                  (1, 12, 272, 144, 6)],
+                         ids=["48x64", "B2_21x32_ragged_rows", "one_band_C136_mid8", "C160_mid3", "width_8_full_strips", "width_272"])
 def test_cab_squeeze_row_sweep(geom):
     """GELU(conv3x3(x) + b) with <= 8 output channels against F.conv2d in fp64 on the bf16-rounded operands, including the
-    per-unit channel sums (their total must equal the sum of the stored fp32 values within bf16 rounding of the outputs)."""
+    per-unit channel sums (their total must equal the sum of the stored fp32 values within bf16 rounding of the outputs).
+    A wave's strip is 14 output columns (16 loaded ones, the dx taps are lane shifts): the widths cover a last strip of 2, 4,
+    6 and 8 columns, a width of exactly eight strips (the last strip's right halo column is outside the image) and 20 strips."""
     dev = _dev()
     ops = _ops()
     from super_resolution_amd._lib import HAT_BF16
