@@ -249,7 +249,7 @@ def test_unfused_tail_switches_keep_the_13x13_conv_on_fresh_rows(monkeypatch, sw
     copy — the engine must then not hand the group conv's stale copy to the next block's 13x13 conv.  Held against the
     reference golden at the bf16 bar and against the default sequence (two bf16 evaluations that round at different places —
     hat_ffn keeps the hidden tensor in bf16, the default tail in fp16 with LayerNorm2's affine folded into fc1: measured 43.8 to
-    47 dB; the stale-copy bug this test is for gave < 30 dB)."""
+    47 dB, bar 42; what a stale copy costs was not measured — the golden crops at the 40 dB / 0.08 bar are the actual guard)."""
     dev = _dev()
     g = golden("summary_HAT-S_x4_64.npz")
     x = synth.synth_input(X_SEED, tuple(int(v) for v in g["x_shape"])).to(dev)
