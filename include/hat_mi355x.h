@@ -156,6 +156,11 @@ typedef struct HatCabFoldDesc {
      * frame, [8,40) over its first row, last row, first column, last column, [40,72) its four corner pixels (top-left,
      * top-right, bottom-left, bottom-right).  H, W are then the FULL frame's; c1, c1_colsum, tmp are not read. */
     const float* stats;
+    /* optional: W2 once more, in wf's own order, fp32 [nt][3][64][8] with element (t, ks, lane, j) = W2[16 t + (lane & 15)][ci = j]
+     * [tap = 4 ks + (lane >> 4)] (zero where co >= C, tap >= 9 or ci >= mid).  The kernel then reads the weights it scales with
+     * unit stride (it is ONE workgroup on the critical chain of a block: the gather out of the [C][mid][3][3] layout was half
+     * of its time).  NULL: gather from w2. */
+    const float* w2f;
 } HatCabFoldDesc;
 int hat_cab_fold(const HatCabFoldDesc* d, void* stream);
 

@@ -84,7 +84,7 @@ class HatCabFoldDesc(C.Structure):
         ("bias_in", C.c_void_p), ("scale", C.c_void_p), ("wf", C.c_void_p), ("bias_out", C.c_void_p), ("tmp", C.c_void_p),
         ("B", C.c_int32), ("H", C.c_int32), ("W", C.c_int32), ("C", C.c_int32), ("mid", C.c_int32), ("ld1", C.c_int32),
         ("tiles", C.c_int32), ("ldcs", C.c_int32), ("k", C.c_int32), ("ld_scale", C.c_int32), ("dtype", C.c_int32),
-        ("conv_scale", C.c_float), ("stats", C.c_void_p),
+        ("conv_scale", C.c_float), ("stats", C.c_void_p), ("w2f", C.c_void_p),
     ]
 
 

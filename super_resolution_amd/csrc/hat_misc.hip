@@ -356,8 +356,23 @@ __global__ __launch_bounds__(256) void cab_fold_kernel(const HatCabFoldDesc d) {
         // costs a full L2 round trip)
         const int co = tid < C ? tid : C - 1;
         float wv[72];
+        if (d.w2f != nullptr) {
+            // fragment order: the 8 ci of (co, tap) are contiguous and the 16 co of a tile 32 bytes apart — unit-stride reads where
+            // the [C][mid][3][3] layout made every thread walk its own 216-byte row
+            const f32x4* wf4 = reinterpret_cast<const f32x4*>(d.w2f) + (size_t)(co >> 4) * (3 * 64 * 2);
+            f32x4 w8[9][2];
 #pragma unroll
-        for (int q = 0; q < 72; ++q) wv[q] = d.w2[(size_t)co * mid * 9 + min(q, mid * 9 - 1)];
+            for (int tap = 0; tap < 9; ++tap) {
+                const int e = ((tap >> 2) * 64 + (tap & 3) * 16 + (co & 15)) * 2;
+                w8[tap][0] = wf4[e];
+                w8[tap][1] = wf4[e + 1];
+            }
+#pragma unroll
+            for (int q = 0; q < 72; ++q) { const int ci = q / 9, tap = q - ci * 9; wv[q] = w8[tap][ci >> 2][ci & 3]; }   // (zero for ci >= mid)
+        } else {
+#pragma unroll
+            for (int q = 0; q < 72; ++q) wv[q] = d.w2[(size_t)co * mid * 9 + min(q, mid * 9 - 1)];
+        }
         const float bb = d.b2[co];
 #pragma unroll
         for (int q = 0; q < 72; ++q) {
@@ -383,6 +398,35 @@ __global__ __launch_bounds__(256) void cab_fold_kernel(const HatCabFoldDesc d) {
     const int nt = (C + 15) / 16;
     for (int n = tid; n < nt * 16; n += 256) d.bias_out[(size_t)b * nt * 16 + n] = n < C ? d.bias_in[n] + scl[n] * d.b2[n] : 0.f;
     T* wf = reinterpret_cast<T*>(d.wf) + (size_t)b * nt * 3 * 512;
+    if (d.w2f != nullptr) {
+        // four consecutive elements per thread and step (one output channel, four ci), every step's 16-byte load issued before
+        // the first product: one round trip for the whole image
+        constexpr int MAXS = 16;   // 4 * 256 * 16 elements per pass
+        const int total4 = nt * 3 * 128;
+        for (int base = 0; base < total4; base += 256 * MAXS) {   // (one pass up to C = 160)
+        f32x4 wq[MAXS];
+#pragma unroll
+        for (int st = 0; st < MAXS; ++st) wq[st] = reinterpret_cast<const f32x4*>(d.w2f)[min(base + tid + st * 256, total4 - 1)];
+#pragma unroll
+        for (int st = 0; st < MAXS; ++st) {
+            const int i4 = base + tid + st * 256;
+            if (i4 < total4) {
+                const int i = 4 * i4, j = i & 7, lane = (i >> 3) & 63, ks = (i >> 9) % 3, t = i / (3 * 512);
+                const int co = t * 16 + (lane & 15), tap = 4 * ks + (lane >> 4);
+                const int cov = min(co, C - 1);
+                const float sv = scl[cov];
+                f32x4 v = wq[st] * f32x4{sv, sv, sv, sv};
+                if (co < C && tap == 9 && j == 0) {   // k = 72, 73: the folded bias, head and remainder (see below)
+                    const float bfull = d.bias_in[cov] + sv * d.b2[cov];
+                    v[0] = bfull;
+                    v[1] = bfull - to_f(to_T<T>(bfull));
+                }
+                Vec4<T>::store(wf + i, v);
+            }
+        }
+        }
+        return;
+    }
     constexpr int FU = 18;  // elements per thread per batch (13 824 elements at C = 144: three batches)
     for (int i0 = tid; i0 < nt * 3 * 512; i0 += 256 * FU) {
         float wv[FU], bi[FU], b2v[FU];

@@ -173,7 +173,7 @@ class HATEngine:
                 if (hb["esc"].aggr.frag and not hb["cab0"].frag and ops.aggr_cab_supported(C, w2raw.shape[1], dt)
                         and not os.environ.get("HAT_NO_CAB_FOLD")):
                     hb["fold"] = {"w2": w2raw.detach().to(**f32).contiguous(), "b2": vec(p + ".conv_block.cab.2.bias"),
-                                  "ba": vec(hb["esc"].aggr_keys[1])}
+                                  "ba": vec(hb["esc"].aggr_keys[1]), "w2f": ops.pack_cab_w2f(w2raw, dev)}
                     # squeeze conv on the row-sweep kernel (no LDS operand traffic) where it is instantiated
                     if ops.cab_squeeze_supported(C, w2raw.shape[1], 16, dt) and not os.environ.get("HAT_NO_CAB_SWEEP"):
                         hb["fold"]["sq"] = ops.pack_cab_squeeze(sd[p + ".conv_block.cab.0.weight"], sd[p + ".conv_block.cab.0.bias"], dev)
@@ -575,7 +575,7 @@ class HATEngine:
                         if bd is None:
                             ops.cab_fold(w["c1"], w["colsum1"], w["tiles1"], hb["cab0"].npad, fo["w2"], fo["b2"], hb["eca_w"],
                                          hb["eca_w"].numel(), fo["ba"], float(cfg["conv_scale"]), w["scale"], w["wf"], w["bias_b"],
-                                         w["eca_tmp"], B=B, H=H, W=W, C_=C, mid=mid, dtype=dt)
+                                         w["eca_tmp"], B=B, H=H, W=W, C_=C, mid=mid, dtype=dt, w2f=fo["w2f"])
                     if bd is not None:
                         # band-sharded: the sums hat_cab_fold takes from c1 (hat_arch.py:73 via the linearity of the expand conv)
                         # are this band's share of [total | first row | last row | first column | last column | 4 corners]
@@ -595,7 +595,7 @@ class HATEngine:
                         yield ("reduce", [(w["gstat_l"], w["gstat_g"], esc.pdim), (st, w["cstat_g"], 72)])
                         ops.cab_fold(None, None, 1, hb["cab0"].npad, fo["w2"], fo["b2"], hb["eca_w"], hb["eca_w"].numel(), fo["ba"],
                                      float(cfg["conv_scale"]), w["scale"], w["wf"], w["bias_b"], None, B=B, H=bd.Hfull, W=W, C_=C,
-                                     mid=mid, dtype=dt, stats=w["cstat_g"])
+                                     mid=mid, dtype=dt, stats=w["cstat_g"], w2f=fo["w2f"])
                         self._esc_w(esc, w, B, bd.Hfull, W, 1, gap=gapb)
                         self._esc_conv(esc, w, w["n"], B, H, W, n16=(w["n16"] if have_n16 else None))
                     elif os.environ.get("HAT_ESC_SIDE") == "1":

@@ -858,13 +858,30 @@ def aggr_cab_supported(C_: int, mid: int, dtype: int) -> bool:
     return C_ == 144 and mid <= 8 and dtype == HAT_BF16
 
 
+def pack_cab_w2f(w2: torch.Tensor, device) -> torch.Tensor:
+    """(C, mid <= 8, 3, 3) expand-conv weight -> fp32 [nt][3][64][8] in the order of hat_cab_fold's output `wf` (HatCabFoldDesc.w2f)."""
+    w = w2.detach().to(torch.float32).cpu()
+    C_, mid = w.shape[0], w.shape[1]
+    nt = -(-C_ // 16)
+    full = torch.zeros(nt * 16, 12, 8)                     # [co][tap 0..11][ci 0..7]
+    full[:C_, :9, :mid] = w.reshape(C_, mid, 9).permute(0, 2, 1)
+    lane = torch.arange(64)
+    t = torch.arange(nt)[:, None, None, None]
+    ks = torch.arange(3)[None, :, None, None]
+    co = (t * 16 + (lane & 15)[None, None, :, None]).expand(nt, 3, 64, 8)
+    tap = (4 * ks + (lane >> 4)[None, None, :, None]).expand(nt, 3, 64, 8)
+    ci = torch.arange(8)[None, None, None, :].expand(nt, 3, 64, 8)
+    return full[co, tap, ci].contiguous().to(device)
+
+
 def cab_fold(c1, c1_colsum, tiles: int, ldcs: int, w2, b2, wk, k: int, bias_in, conv_scale: float, scale, wf, bias_out, tmp, *,
-             B: int, H: int, W: int, C_: int, mid: int, dtype: int, stats=None):
+             B: int, H: int, W: int, C_: int, mid: int, dtype: int, stats=None, w2f=None):
     """stats: (B, >= 72) fp32 = the frame-wide sums of c1 ([total 8 | first row | last row | first column | last column | four
     corner pixels]); H, W are then the FULL frame's and c1 / c1_colsum are not read (band-sharded frames)."""
     lib = _lib.load()
     d = HatCabFoldDesc()
     d.stats = _ptr(stats)
+    d.w2f = _ptr(w2f)
     d.c1, d.c1_colsum, d.w2, d.b2, d.wk, d.bias_in = _ptr(c1), _ptr(c1_colsum), _ptr(w2), _ptr(b2), _ptr(wk), _ptr(bias_in)
     d.scale, d.wf, d.bias_out, d.tmp = _ptr(scale), _ptr(wf), _ptr(bias_out), _ptr(tmp)
     d.B, d.H, d.W, d.C, d.mid, d.ld1, d.tiles, d.ldcs, d.k, d.ld_scale, d.dtype = B, H, W, C_, mid, 8, tiles, ldcs, k, scale.shape[1], dtype
