@@ -888,6 +888,9 @@ def test_cab_squeeze_row_sweep(geom):
     tot = cs.sum(1).cpu()
     assert float(tot[:, 8:].abs().max()) == 0.0
     assert torch.allclose(tot[:, :mid].double(), ref.sum((1, 2)), rtol=2e-3, atol=2e-2 * (H * W) ** 0.5)
+    # ... and they are the sums of the STORED values (what a band-sharded frame pools with hat_rect_sum): fp32 round-off only
+    stored = got[..., :mid].double().sum((1, 2))
+    assert float((cs.double().sum(1).cpu()[:, :mid] - stored).abs().max()) <= 2e-6 * float(got[..., :mid].double().abs().sum((1, 2)).max())
 
 
 @pytest.mark.parametrize("geom", [(1, 40, 64, 3), (2, 19, 32, 3), (1, 64, 48, 1)], ids=["40x64", "B2_19x32", "one_channel"])

@@ -36,7 +36,7 @@ def main():
         dt = time.time() - t0
         err = float((y1 - y0).abs().max())
         res.append((name, dtype, shape, world, "max-abs %.3e" % err, "psnr %.1f dB" % O.psnr_float(y1.cpu(), y0.cpu()), "%.2f s" % dt))
-        ok = err <= 1e-5 if dtype == "f32" else O.psnr_float(y1.cpu(), y0.cpu()) >= (60.0 if shape[2] < 720 else 43.0)
+        ok = err <= 1e-5 if dtype == "f32" else O.psnr_float(y1.cpu(), y0.cpu()) >= (48.0 if shape[2] < 720 else 43.0)   # (bars of tests/test_gpu_bands.py)
         assert ok, res[-1]
     dist.barrier()
     if rank == 0:
