@@ -18,6 +18,26 @@
 
 namespace {
 
+// LDS fragment address for a compile-time byte offset, from one of three per-lane bases 60 KiB apart: a DS instruction's
+// immediate offset is 16 bits, and with ONE base the compiler re-creates a base register (a v_add) for every fragment beyond
+// 64 KiB — 88 of the 1 090 vector instructions per tile in the MLP kernel, whose fragments fill the LDS.
+struct LdsBases { unsigned b0, b1, b2; };
+constexpr unsigned LB_STEP = 61440;
+__device__ __forceinline__ LdsBases lds_bases(const char* lane_base) {
+    typedef __attribute__((address_space(3))) char lds_char;
+    LdsBases r;
+    r.b0 = (unsigned)(uintptr_t)(lds_char*)lane_base;
+    r.b1 = r.b0 + LB_STEP;
+    r.b2 = r.b0 + 2 * LB_STEP;
+    asm volatile("" : "+v"(r.b0), "+v"(r.b1), "+v"(r.b2));   // (opaque: three registers, not one base + re-materialised sums)
+    return r;
+}
+template <typename V> __device__ __forceinline__ V lds_at(const LdsBases& lb, unsigned off) {
+    const unsigned base = off < LB_STEP ? lb.b0 : (off < 2 * LB_STEP ? lb.b1 : lb.b2);
+    const unsigned rel = off < LB_STEP ? off : (off < 2 * LB_STEP ? off - LB_STEP : off - 2 * LB_STEP);
+    return *(__attribute__((address_space(3))) const V*)(uintptr_t)(base + rel);
+}
+
 constexpr int ML_C = 144, ML_HID = 288, ML_NT1 = ML_HID / 16, ML_NT2 = ML_C / 16, ML_KK = ML_HID / 32;   // 18, 9, 9
 constexpr int ML_W1F = ML_NT1 * 4 * 1024;          // fc1 full fragments  [nt][ks 0..3][64 lanes][8]      73728
 constexpr int ML_W1H = ML_NT1 * 512;               // fc1 half fragments  [nt][64 lanes][4] (channels 128..143)  9216
@@ -90,6 +110,7 @@ __global__ __launch_bounds__(WAVES * 64) void ocab_mlp_kernel(const HatMlpDesc d
         asm volatile("" : "+v"(wofs));
         const char* wl = smem + wofs;
         const char* wl8 = smem + ML_OFF_W1H + (wofs >> 1);   // the half fragments: 8 bytes per lane
+        const LdsBases lb = lds_bases(wl), lb8 = lds_bases(smem + (wofs >> 1));
         // Weight fragments are requested ahead of their MFMAs into their own registers — fc1: the five fragments + bias of channel
         // tile nt + 1 while tile nt's five MFMAs run; fc2: a four-deep ring, three fragments ahead — and the scheduler may not move
         // anything across a step (sched_barrier).  Left to itself it reads each fragment right before its MFMA and drains the LDS
@@ -101,10 +122,10 @@ __global__ __launch_bounds__(WAVES * 64) void ocab_mlp_kernel(const HatMlpDesc d
             struct W1 { s16x4 h; f32x4 b; frag_t f[4]; };
             W1 ws[2];
             auto rd1 = [&](int nt, W1& w) {
-                w.h = *reinterpret_cast<const s16x4*>(wl8 + nt * 512);
+                w.h = lds_at<s16x4>(lb8, ML_OFF_W1H + nt * 512);
                 w.b = *reinterpret_cast<const f32x4*>(b1l + nt * 16 + 4 * g);
 #pragma unroll
-                for (int ks = 0; ks < 4; ++ks) w.f[ks] = *reinterpret_cast<const frag_t*>(wl + (nt * 4 + ks) * 1024);
+                for (int ks = 0; ks < 4; ++ks) w.f[ks] = lds_at<frag_t>(lb, (nt * 4 + ks) * 1024);
             };
             rd1(0, ws[0]);
             f32x4 a[2];
@@ -135,7 +156,7 @@ __global__ __launch_bounds__(WAVES * 64) void ocab_mlp_kernel(const HatMlpDesc d
         {
             constexpr int NF = ML_NT2 * ML_KK - ML_NREG, AD = 3;   // fragments that live in LDS; ring depth
             frag_t ring[AD + 1];
-            auto rd2 = [&](int f) { ring[f % (AD + 1)] = *reinterpret_cast<const frag_t*>(wl + ML_OFF_W2 + f * 1024); };
+            auto rd2 = [&](int f) { ring[f % (AD + 1)] = lds_at<frag_t>(lb, ML_OFF_W2 + f * 1024); };
 #pragma unroll
             for (int f = 0; f < AD; ++f) rd2(f);
 #pragma unroll
@@ -220,6 +241,7 @@ __global__ __launch_bounds__(WAVES * 64) void ocab_qkv_kernel(const HatMlpDesc d
         asm volatile("" : "+v"(wofs));   // (keeps the loop-invariant fragment reads inside the loop)
         const char* wl = smem + wofs;
         const char* wl8 = smem + QK_WF + (wofs >> 1);
+        const LdsBases lb = lds_bases(wl), lb8 = lds_bases(smem + (wofs >> 1));
         bf16_t* o = reinterpret_cast<bf16_t*>(d.out) + pc * d.ldo;
         // channel tiles in pairs: results leave as 16-byte stores while the next pair's MFMAs run.  The five weight fragments +
         // bias of channel tile nt + 1 are requested while tile nt's five MFMAs run, order pinned (see ocab_mlp_kernel).
@@ -227,10 +249,10 @@ __global__ __launch_bounds__(WAVES * 64) void ocab_qkv_kernel(const HatMlpDesc d
         struct W1 { s16x4 h; f32x4 b; frag_t f[4]; };
         W1 ws[2];
         auto rd1 = [&](int nt, W1& w) {
-            w.h = *reinterpret_cast<const s16x4*>(wl8 + nt * 512);
+            w.h = lds_at<s16x4>(lb8, QK_WF + nt * 512);
             w.b = *reinterpret_cast<const f32x4*>(bl + nt * 16 + 4 * g);
 #pragma unroll
-            for (int ks = 0; ks < 4; ++ks) w.f[ks] = *reinterpret_cast<const frag_t*>(wl + (nt * 4 + ks) * 1024);
+            for (int ks = 0; ks < 4; ++ks) w.f[ks] = lds_at<frag_t>(lb, (nt * 4 + ks) * 1024);
         };
         rd1(0, ws[0]);
         f32x4 a[2];
