@@ -55,8 +55,11 @@ __global__ __launch_bounds__((E_TR / RW) * 64) void esc13_kernel(const bf16_t* _
     }
     const int r0 = RW * wave;
     // lane (p, g): pixel column c16 + (g >> 1) (the second tap of a pair is one column further), channel half g & 1
-    const unsigned xbase = lds0 + E_X_OFF + (unsigned)((r0 * E_HC + c16 + (g >> 1)) * 32 + (g & 1) * 16);
-    const unsigned abase = lds0 + (unsigned)lane * 16u;
+    // (opaque, and TWO bases for the 91 KiB of weight fragments: a DS instruction's immediate offset is 16 bits; derived from one
+    // visible base the compiler re-created an address with a v_add for 268 of a tile's 323 reads)
+    unsigned xbase = lds0 + E_X_OFF + (unsigned)((r0 * E_HC + c16 + (g >> 1)) * 32 + (g & 1) * 16);
+    unsigned abase = lds0 + (unsigned)lane * 16u, abase1 = abase + 60u * 1024u;
+    asm volatile("" : "+v"(xbase), "+v"(abase), "+v"(abase1));
 
     // The next tile's haloed input is fetched into registers BEFORE this tile's K loop and written to LDS after it: with one
     // workgroup per CU nothing else would cover that latency.
@@ -99,7 +102,8 @@ __global__ __launch_bounds__((E_TR / RW) * 64) void esc13_kernel(const bf16_t* _
         // (sched_barrier): left alone it hoists a column pair's 45 reads above the first MFMA — 144 registers for RW = 4,
         // where 128 is what lets two of these waves share a SIMD with a wave of the CAB squeeze conv (hat_cabsq.hip).
         auto lda = [&](int dxp, int dy) {
-            return __builtin_bit_cast(bf8, *(__attribute__((address_space(3))) const u32x4*)(uintptr_t)(abase + (unsigned)((dxp * 13 + dy) * 1024)));
+            const int sfr = dxp * 13 + dy;
+            return __builtin_bit_cast(bf8, *(__attribute__((address_space(3))) const u32x4*)(uintptr_t)(sfr < 60 ? abase + (unsigned)(sfr * 1024) : abase1 + (unsigned)((sfr - 60) * 1024)));
         };
         bf8 rowf[7][RW + 12][2];   // [column pair][input row r0 + i][column tile] (fully unrolled: RW + 1 rows live at a time)
         bf8 afr[7][13];
