@@ -116,3 +116,22 @@ def test_bench_self_launches_its_ranks():
     assert r.returncode != 0
     assert r.stderr.count("bench.py needs an MI355X") >= 2, r.stderr[-2000:]
     assert "WORLD_SIZE=1" not in r.stderr
+
+
+def test_pack_cab_w2f_is_the_expand_weight_in_fragment_order():
+    """ops.pack_cab_w2f (HatCabFoldDesc.w2f, include/hat_mi355x.h): element (t, ks, lane, j) of the fp32 image is
+    W2[16 t + lane % 16][ci = j][tap = 4 ks + lane // 16] (hat_arch.py:86's 3x3 expand conv) and zero where the output
+    channel, the tap or the input channel does not exist — the order of hat_cab_fold's output, so that the kernel reads it
+    with unit stride.  Host-side packing only: runs without a GPU."""
+    from super_resolution_amd import ops
+    g = torch.Generator().manual_seed(7)
+    for C_, mid in ((144, 6), (160, 8), (136, 3)):
+        w2 = torch.randn(C_, mid, 3, 3, generator=g)
+        f = ops.pack_cab_w2f(w2, "cpu")
+        nt = -(-C_ // 16)
+        assert f.shape == (nt, 3, 64, 8) and f.dtype == torch.float32
+        for (t, ks, lane, j) in [(0, 0, 0, 0), (nt - 1, 2, 63, 7), (3, 1, 17, 2), (nt - 1, 0, 15, mid - 1), (1, 2, 16, 0), (2, 2, 5, 1)]:
+            co, tap = 16 * t + lane % 16, 4 * ks + lane // 16
+            want = float(w2[co, j, tap // 3, tap % 3]) if (co < C_ and tap < 9 and j < mid) else 0.0
+            assert float(f[t, ks, lane, j]) == want, (C_, mid, t, ks, lane, j)
+        assert float(f.abs().sum()) == pytest.approx(float(w2.abs().sum()), rel=1e-6)
