@@ -38,6 +38,11 @@ def _r4(x: int) -> int:
     return (x + 3) // 4 * 4
 
 
+# HAT_EMU_T16=fp16|bf16: round the fp32 residual stream to that type after every HAB tail and group conv (a torch copy:
+# slower, NOT a product path) — the parity cost of a 16-bit residual stream, measured before anyone builds it.
+_EMU_T16 = {"fp16": torch.float16, "bf16": torch.bfloat16}.get(os.environ.get("HAT_EMU_T16", ""))
+
+
 class _ESC:
     """Packed parameters of one ConvAttnWrapper (esc_arch.py:136-145) + its large-kernel filter."""
 
@@ -622,6 +627,8 @@ class HATEngine:
                                      c1=w["c1"], wf=w["wf"], bias_b=w["bias_b"], B=B, H=H, W=W, dtype=dt, ln1=nxt, n_out=w["n2b"],
                                      ldn=ldc, gap_out=w["gap"], gap_c=gap_c, n16_out=(w["n16"] if self.use_n16 else None))
                         w["n"], w["n2b"] = w["n2b"], w["n"]      # the kernel reads n with a halo: its output n' is another buffer
+                        if _EMU_T16 is not None:   # measurement only (tools/residual16_psnr.py): what a 16-bit residual stream would cost
+                            tout.copy_(tout.to(_EMU_T16).to(torch.float32))
                         t, have_n, nblk = tout, True, ops.ffn_tiles(hb["ffn"], H, W, dt)
                         have_n16 = self.use_n16
                         continue
@@ -724,6 +731,8 @@ class HATEngine:
                     ops.conv(L["conv"], tout, tA, **geo, ldx=ldc, ldo=C, x_mode=X_NHWC_T, out_mode=O_NHWC_F32, r1=tA, ldr1=C, **lnkw)
                 else:
                     ops.conv(L["conv"], tout, tA, **geo, ldx=C, ldo=C, x_mode=X_NHWC_F32, out_mode=O_NHWC_F32, r1=tA, ldr1=C, **lnkw)
+                if _EMU_T16 is not None:
+                    tA.copy_(tA.to(_EMU_T16).to(torch.float32))
         # final LN; conv_after_body + f0 ; conv_before_upsample + LeakyReLU                :844, :854-855
         if self.conv_after_body is None:   # nn.Identity: LN(t) + f0 in fp32, read as such by the next conv      :748
             ln(tA, tB, self.norm, out_f32=True)
