@@ -453,7 +453,9 @@ typedef struct HatHabTailDesc {
     const void* r2;             /* (B,H,W,ldr2) T: c2 = conv3x3(c1) + b2 */
     const float* r2scale;       /* [B][r2scale_bstride] fp32: conv_scale * ECA(c2); 1 KiB must be readable from every sample's row */
     int32_t r2scale_bstride;
-    int32_t reserved1;
+    int32_t reserved1;          /* hat_hab_tail3 at embed_dim 144: bit 0 = ffn.t_in, bit 1 = ffn.t_out are FP16 rows (B,H,W,C) instead of
+                                 * fp32 ones (a 16-bit residual stream between the blocks of a group; values are clamped to the finite
+                                 * FP16 range when written); 0 everywhere else */
 } HatHabTailDesc;
 int hat_hab_tail(const HatHabTailDesc* d, void* stream);
 

@@ -93,7 +93,10 @@ __device__ __attribute__((aligned(16))) unsigned hat_tail3_zero_page[4] = {0, 0,
 __device__ __attribute__((aligned(16))) unsigned hat_tail3_ones_page[4] = {0x3F803F80u, 0, 0, 0};   // bf16 {1, 1, 0 ...}
 
 // DBG 64: per-phase s_memtime totals of every wave -> gap_out[wg][wave][12] (tools/ubench_tail3.hip; the library builds 0)
-template <int DBG>
+// TH: the residual stream's type — bit 0: t_in is FP16 rows, bit 1: t_out is FP16 rows (else fp32).  Between two HABs of a group
+// the stream is read and written by this kernel only; 16 bits there take 4C of a pixel's 12.3C bytes away at 0.1 dB
+// (profiles/r03_residual16_emulation.txt).  FP16, not bf16 (2.9 dB); values are clamped to the finite FP16 range on the way out.
+template <int DBG, int TH = 0>
 __global__ __launch_bounds__(256, 2) void tail3_kernel(const HatFfnDesc d, const T3Aggr ag) {
     constexpr int C = T3_C, NT = T3_NT, KS = T3_KS, NPH = T3_NPH, HALO_W = T3_HW;
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -104,6 +107,7 @@ __global__ __launch_bounds__(256, 2) void tail3_kernel(const HatFfnDesc d, const
     const int b = blockIdx.z, x0 = blockIdx.x * 16, y0 = blockIdx.y * T3_ROWS;
     const int H = d.H, W = d.W;
     const float* tin = d.t_in + (size_t)b * H * W * C;
+    const _Float16* tinh = reinterpret_cast<const _Float16*>(d.t_in) + (size_t)b * H * W * C;
 
     long long tph[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
     long long tlast = 0;
@@ -169,6 +173,8 @@ __global__ __launch_bounds__(256, 2) void tail3_kernel(const HatFfnDesc d, const
         bool ins[3];
         bf8 bfr[3][8];
         f32x4 accx[NT];
+        typedef unsigned u32x2h __attribute__((ext_vector_type(2)));
+        u32x2h thr[3][TH & 1 ? NT : 1];   // TH & 1: the FP16 residual rows of the wave's three pixel tiles, raw
         const bf16_t* nb = ag.n + (size_t)b * H * W * ag.ldn;
         const bf16_t* yb = ag.y16 + (size_t)b * H * W * 16;
         const bf16_t* cb = ag.c1 + (size_t)b * H * W * 8;
@@ -204,8 +210,12 @@ __global__ __launch_bounds__(256, 2) void tail3_kernel(const HatFfnDesc d, const
             }
 #pragma unroll
             for (int nt = 0; nt < NT; ++nt) {
-                const f32x4 tv = *reinterpret_cast<const f32x4*>(tin + (size_t)pix * C + nt * 16 + 4 * g);
-                if (t < 2) acc2[nt][t] = tv; else accx[nt] = tv;
+                if constexpr (TH & 1) {   // 4 halves: they wait as raw bits until their tile's turn (converted in front of its MFMAs)
+                    thr[t][nt] = *reinterpret_cast<const u32x2h*>(tinh + (size_t)pix * C + nt * 16 + 4 * g);
+                } else {
+                    const f32x4 tv = *reinterpret_cast<const f32x4*>(tin + (size_t)pix * C + nt * 16 + 4 * g);
+                    if (t < 2) acc2[nt][t] = tv; else accx[nt] = tv;
+                }
             }
             __builtin_amdgcn_sched_barrier(0);
         };
@@ -225,7 +235,14 @@ __global__ __launch_bounds__(256, 2) void tail3_kernel(const HatFfnDesc d, const
             // 72 MFMAs against the resident A operands, fragment reads three ahead
             f32x4 v[NT];
 #pragma unroll
-            for (int nt = 0; nt < NT; ++nt) v[nt] = t == 2 ? accx[nt] : acc2[nt][t];
+            for (int nt = 0; nt < NT; ++nt) {
+                if constexpr (TH & 1) {
+                    const h2 lo = as_h2(thr[t][nt][0]), hi = as_h2(thr[t][nt][1]);
+                    v[nt] = f32x4{(float)lo[0], (float)lo[1], (float)hi[0], (float)hi[1]};
+                } else {
+                    v[nt] = t == 2 ? accx[nt] : acc2[nt][t];
+                }
+            }
             // (A fragment reads T3_S0RD MFMAs ahead of their use, the order pinned: left to the scheduler each read is sunk to
             // just before its MFMA — one LDS latency per MFMA, 22 k cycles for the 216 of them in the first build)
             constexpr int RD = T3_S0RD;
@@ -479,8 +496,19 @@ __global__ __launch_bounds__(256, 2) void tail3_kernel(const HatFfnDesc d, const
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) {
             const f32x4 v = acc2[nt][pt];
-            if (valid) *reinterpret_cast<f32x4*>(tout + pix * C + nt * 16 + 4 * g) = v;
+            if constexpr (!(TH & 2)) { if (valid) *reinterpret_cast<f32x4*>(tout + pix * C + nt * 16 + 4 * g) = v; }
             s += (v[0] + v[1]) + (v[2] + v[3]);
+        }
+        if constexpr ((TH & 2) != 0) {   // FP16 rows: n-tile pairs as 16-byte stores, the last tile as an 8-byte one
+            _Float16* trow = reinterpret_cast<_Float16*>(d.t_out) + ((size_t)b * H * W + pix) * C;
+#pragma unroll
+            for (int nt = 0; nt + 1 < NT; nt += 2) store_pair_f16_if(trow, nt * 16, g, acc2[nt][pt], acc2[nt + 1][pt], valid);
+            if (valid) {
+                typedef _Float16 v4h __attribute__((ext_vector_type(4)));
+                const f32x4 v = acc2[NT - 1][pt];
+                auto c = [](float x) { return (_Float16)__builtin_amdgcn_fmed3f(x, -65504.0f, 65504.0f); };
+                *reinterpret_cast<v4h*>(trow + (NT - 1) * 16 + 4 * g) = v4h{c(v[0]), c(v[1]), c(v[2]), c(v[3])};
+            }
         }
         if (do_ln) {  // LayerNorm (eps 1e-5) of the finished pixel for the next block; 4 lane groups share a pixel
             s += __shfl_xor(s, 16); s += __shfl_xor(s, 32);
@@ -561,13 +589,18 @@ extern "C" int hat_hab_tail3(const HatHabTailDesc* dp, void* stream) {
     if (!d.t_in || !d.t_out || d.t_in == d.t_out || !d.w1f || !d.dww || !d.w2f || !d.b2) return HAT_EINVAL;
     if (d.B < 1 || d.H < 1 || d.W < 1 || d.chunks < 1 || d.m_in) return HAT_EINVAL;
     if (d.dtype != HAT_BF16) return HAT_EUNSUPPORTED;
-    if (d.C == 180) return d.chunks == 12 ? hat_tail3_launch_c180(h, stream) : HAT_EINVAL;
+    if (d.C == 180) return (d.chunks == 12 && h.reserved1 == 0) ? hat_tail3_launch_c180(h, stream) : HAT_EINVAL;
     if (d.C != T3_C) return HAT_EUNSUPPORTED;
     if (d.ln1_g && (!d.ln1_b || !d.n_out || d.ldn < d.C || d.ldn % 4 || d.gap_c < 0 || d.gap_c > 16 || d.gap_c % 4)) return HAT_EINVAL;
     if (!h.n || !h.y16 || !h.c1 || !h.w_aggr || !h.wf || !h.bias_b || h.ldn_in < T3_C || h.ldn_in % 8) return HAT_EINVAL;
     const T3Aggr ag{reinterpret_cast<const bf16_t*>(h.n), reinterpret_cast<const bf16_t*>(h.y16), reinterpret_cast<const bf16_t*>(h.c1),
                     reinterpret_cast<const char*>(h.w_aggr), reinterpret_cast<const char*>(h.wf), h.bias_b, h.ldn_in};
-    auto kern = tail3_kernel<0>;
+    // reserved1 bit 0 / bit 1: t_in / t_out are FP16 rows (8-byte aligned for the loads, 16-byte for the paired stores)
+    const int th = h.reserved1 & 3;
+    if ((h.reserved1 & ~3) != 0) return HAT_EINVAL;
+    if ((th & 1) && reinterpret_cast<uintptr_t>(d.t_in) % 8) return HAT_EINVAL;
+    if ((th & 2) && reinterpret_cast<uintptr_t>(d.t_out) % 16) return HAT_EINVAL;
+    void (*kern)(const HatFfnDesc, const T3Aggr) = th == 0 ? tail3_kernel<0, 0> : th == 1 ? tail3_kernel<0, 1> : th == 2 ? tail3_kernel<0, 2> : tail3_kernel<0, 3>;
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, T3_LDS);
     if (e != hipSuccess) return (int)e;
     dim3 grid((d.W + 15) / 16, (d.H + T3_ROWS - 1) / T3_ROWS, d.B);

@@ -713,7 +713,7 @@ def hab_tail(pf: PackedFFN, aggr: PackedConv, t_in, t_out, ln_g, ln_b, *, n, ldn
              W: int, dtype: int, ln1=None, n_out=None, ldn: int = 0, gap_out=None, gap_c: int = 0, n16_out=None,
              r2=None, ldr2: int = 0, r2scale=None, r2scale_bstride: int = 0):
     """hat_hab_tail: aggregation + folded CAB + residuals + the whole gated FFN in one launch (t_in = the residual stream
-    BEFORE the aggregation)."""
+    BEFORE the aggregation).  hat_hab_tail3 at embed_dim 144 takes t_in / t_out as fp32 or FP16 rows (by the tensors' dtype)."""
     lib = _lib.load()
     h = HatHabTailDesc()
     d = h.ffn
@@ -721,6 +721,12 @@ def hab_tail(pf: PackedFFN, aggr: PackedConv, t_in, t_out, ln_g, ln_b, *, n, ldn
     _fill_ffn(d, pf, t_in, t_out, ln_g, ln_b, ln1, n_out, ldn, gap_out, gap_c, n16_out=n16_out)
     h.n, h.y16, h.c1, h.w_aggr, h.wf, h.bias_b, h.ldn_in = _ptr(n), _ptr(y16), _ptr(c1), _ptr(aggr.w), _ptr(wf), _ptr(bias_b), ldn_in
     h.r2, h.ldr2, h.r2scale, h.r2scale_bstride = _ptr(r2), ldr2, _ptr(r2scale), r2scale_bstride
+    in_half, out_half = t_in.dtype == torch.float16, t_out.dtype == torch.float16
+    if (in_half or out_half) and not (pf.C == 144 and pf.khalf == "v3"):
+        raise RuntimeError("an FP16 residual stream is only instantiated for hat_hab_tail3 at embed_dim 144")
+    if (not in_half and t_in.dtype != torch.float32) or (not out_half and t_out.dtype != torch.float32):
+        raise RuntimeError("hab_tail: t_in / t_out must be fp32 or FP16 rows")
+    h.reserved1 = (1 if in_half else 0) | (2 if out_half else 0)
     if pf.C == 180:   # aggregation + c2 term + FFN; n, y16, c2 (T), t read once, t_out and the next LayerNorm written
         flops = B * H * W * (2.0 * pf.C * pf.C + 2.0 * pf.C * 2 * pf.hid + 2.0 * 9 * 2 * pf.hid + 2.0 * pf.hid * pf.C)
         nbytes = B * H * W * (2.0 * ldn_in + 32 + 2.0 * ldr2 + 4.0 * pf.C + 4.0 * pf.C + (2 * ldn if ln1 is not None else 0))
@@ -729,7 +735,7 @@ def hab_tail(pf: PackedFFN, aggr: PackedConv, t_in, t_out, ln_g, ln_b, *, n, ldn
     flops = B * H * W * (2.0 * pf.C * (pf.C + 72) + 2.0 * pf.C * 2 * pf.hid + 2.0 * 9 * 2 * pf.hid + 2.0 * pf.hid * pf.C)
     # algorithmic HBM bytes per pixel: n (T), y16 (T x 16), c1 (T x 8), t (fp32) read once; t_out (fp32) and the next
     # block's LayerNorm output (T) written
-    nbytes = B * H * W * (2.0 * ldn_in + 32 + 16 + 4.0 * pf.C + 4.0 * pf.C + (2 * ldn if ln1 is not None else 0))
+    nbytes = B * H * W * (2.0 * ldn_in + 32 + 16 + (2.0 if in_half else 4.0) * pf.C + (2.0 if out_half else 4.0) * pf.C + (2 * ldn if ln1 is not None else 0))
     if pf.khalf == "v3":
         _timed("tail3_kernel", flops, lambda: _lib.check(lib.hat_hab_tail3(C.byref(h), _stream()), "hat_hab_tail3"), nbytes=nbytes)
         return

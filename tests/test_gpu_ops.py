@@ -789,6 +789,65 @@ def test_hab_tail_fused(geom, gen):
     check(n1.float(), ref_n, "bf16", "hab tail next-LN")
 
 
+@pytest.mark.parametrize("geom", [(2, 24, 40), (1, 19, 27)], ids=["B2_24x40", "ragged_19x27"])
+def test_hab_tail3_fp16_residual_rows(geom):
+    """hat_hab_tail3 with the residual stream as FP16 rows (HatHabTailDesc.reserved1 bits 0 / 1; the engine uses them between
+    the blocks of a residual group): the arithmetic is the fp32-stream kernel's, only the load / store differ — FP16 in is
+    exact, FP16 out is round-to-nearest of the same fp32 result.  So on an input that is representable in FP16 all four
+    combinations must agree BIT FOR BIT with the fp32 / fp32 launch (t_out after .half(), the next LayerNorm rows, the GAP
+    partials and the compact copy as they are); and a value beyond the FP16 range is clamped, not turned into inf."""
+    B, H, W = geom
+    C, mid, hid = 144, 6, 288
+    dev, ops = _dev(), _ops()
+    dt, tdt = ops.DTYPE_CODE["bf16"], torch.bfloat16
+    n = q(rnd("hhn", (B, H, W, C)), "bf16")
+    y16 = q(rnd("hhy", (B, H, W, 16)), "bf16")
+    c1 = q(F.gelu(rnd("hhc1", (B, H, W, mid))), "bf16")
+    t16 = (rnd("hht", (B, H, W, C), std=1.5) + 0.3).half()
+    wa, ba = q(rnd("hhwa", (C, C), std=C ** -0.5), "bf16"), rnd("hhba", (C,), std=0.1)
+    sd = {
+        "n2.weight": 1 + rnd("hg", (C,), std=0.1), "n2.bias": rnd("hbb", (C,), std=0.1),
+        "m.fc1.weight": q(rnd("h1w", (2 * hid, C), std=C ** -0.5), "bf16"), "m.fc1.bias": rnd("h1b", (2 * hid,), std=0.1),
+        "m.dw.weight": rnd("hdw", (2 * hid, 1, 3, 3), std=1 / 3).half().float(), "m.dw.bias": rnd("hdb", (2 * hid,), std=0.1).half().float(),
+        "m.fc2.weight": rnd("h2w", (C, hid), std=hid ** -0.5).half().float(), "m.fc2.bias": rnd("h2b", (C,), std=0.1),
+        "n1.weight": 1 + rnd("hg1", (C,), std=0.1), "n1.bias": rnd("hb1", (C,), std=0.1),
+    }
+    pw = ops.pack_linear_weight(wa, ba, dt, dev)
+    pf = ops.pack_ffn3(sd["m.fc1.weight"], sd["m.fc1.bias"], sd["m.dw.weight"], sd["m.dw.bias"], sd["m.fc2.weight"], sd["m.fc2.bias"],
+                       sd["n2.weight"], sd["n2.bias"], dev)
+    c1d = to_dev(c1, 8, tdt, dev)
+    wf = (torch.randn(B, pw.nt * 3 * 512, generator=torch.Generator().manual_seed(5)) * 0.02).to(tdt).to(dev)
+    bias_b = rnd("hhbb", (B, pw.npad), std=0.1).to(dev)
+    nd, yd = to_dev(n, C, tdt, dev), to_dev(y16, 16, tdt, dev)
+    dv = lambda k: sd[k].to(dev).contiguous()
+    tiles = ops.ffn_tiles(pf, H, W, dt)
+    res = {}
+    for in_half in (False, True):
+        for out_half in (False, True):
+            td = t16.reshape(B, H * W, C).to(dev)
+            td = td.contiguous() if in_half else td.float().contiguous()
+            out = torch.full((B, H * W, C), 7.0, dtype=(torch.float16 if out_half else torch.float32), device=dev)
+            n1, gap = torch.zeros(B, H * W, C, dtype=tdt, device=dev), torch.zeros(B, tiles, 16, device=dev)
+            n16 = torch.zeros(B, H * W, 16, dtype=tdt, device=dev)
+            ops.hab_tail(pf, pw, td, out, dv("n2.weight"), dv("n2.bias"), n=nd, ldn_in=C, y16=yd, c1=c1d, wf=wf, bias_b=bias_b, B=B, H=H, W=W,
+                         dtype=dt, ln1=(dv("n1.weight"), dv("n1.bias")), ldn=C, gap_c=16, n_out=n1, gap_out=gap, n16_out=n16)
+            torch.cuda.synchronize()
+            res[(in_half, out_half)] = (out.cpu(), n1.cpu(), gap.cpu(), n16.cpu())
+    o0, n0, g0, s0 = res[(False, False)]
+    assert torch.isfinite(o0).all() and float(o0.abs().max()) < 6e4
+    for key, (o, n1, gap, n16) in res.items():
+        want = o0.half() if key[1] else o0
+        assert torch.equal(o, want), f"t_out differs for (in_half, out_half) = {key}: max-abs {float((o.float() - want.float()).abs().max()):.3e}"
+        assert torch.equal(n1, n0) and torch.equal(gap, g0) and torch.equal(n16, s0), key
+    # beyond the FP16 range: clamped to +-65504
+    td = torch.full((1, 8 * 16, C), 7.0e4, device=dev)
+    out = torch.zeros(1, 8 * 16, C, dtype=torch.float16, device=dev)
+    ops.hab_tail(pf, pw, td, out, dv("n2.weight"), dv("n2.bias"), n=nd[:1, :128].contiguous(), ldn_in=C, y16=yd[:1, :128].contiguous(),
+                 c1=c1d[:1, :128].contiguous(), wf=wf[:1].contiguous(), bias_b=bias_b[:1].contiguous(), B=1, H=8, W=16, dtype=dt)
+    torch.cuda.synchronize()
+    assert torch.isfinite(out).all() and float(out.float().abs().max()) == 65504.0
+
+
 # ------------------------------------------------------------------------------------------------
 # (S)W-MSA branch (SURVEY §8 row f2): hat_linear -> hat_window_attention -> hat_linear
 # ------------------------------------------------------------------------------------------------
