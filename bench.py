@@ -266,6 +266,11 @@ def main():
                         "frac": round(tflops / peak_tf, 4), "traffic": None}
         roofline.update({"launches_per_step": e[0] // reps, "avg_launch_ms": round(e[1] / e[0], 4),
                          "flop_per_launch": round(e[2] / e[0] / 1e9, 3), "flop_unit": "GFLOP (algorithmic, 2*MAC)"})
+        if dom == "tail3_kernel" and roofline["bound"] == "hbm":
+            # continuity with rounds 1-3a: until the residual stream between two tails became FP16 rows the same launch needed
+            # 1776 B per pixel; `frac` above is on the bytes it needs NOW (1200 / 1488 B per pixel by launch)
+            ref_b = frames_per_step / world * H * W * 1776.0
+            roofline["frac_on_fp32_stream_bytes"] = round(ref_b / avg_s / 1e9 / HBM_PEAK_GBS, 4)
         # HBM bytes per launch from the PMC counters: measured in separate rocprofv3 --pmc passes (profiles/README.md)
         # and recorded in profiles/; quoted only when the recording is of this exact workload
         try:
